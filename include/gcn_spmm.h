@@ -1,0 +1,135 @@
+/*
+ * gcn_spmm.h — C-ABI of the MI355X (gfx950) GraphConvolution hot path.
+ *
+ * This is the drop-in boundary for the sparse x dense products of LinChen-65/pygcn's
+ * GraphConvolution layer.  The reference has no FFI of its own for this path: it calls PyTorch,
+ *
+ *     output = torch.spmm(adj, support)              pygcn/layers.py:34     (forward,  A · B)
+ *     grad_support = adj.t() @ grad_output           torch autograd `mm` mat2 formula, triggered
+ *                                                    by loss.backward() at pygcn/train.py:157
+ *     output + self.bias                             pygcn/layers.py:35-36  (fused epilogue)
+ *
+ * so the entry points below are what a binding for those three lines has to call.  Plain
+ * pointers and sizes only — no torch types.  Every `const void*`/pointer marked DEVICE must be
+ * hipMalloc'ed memory of the current device; the launchers never allocate, never synchronise
+ * and enqueue on the stream they are given (so they are hipGraph-capturable).  The planner
+ * entry points (`*_host`) are pure CPU code on HOST arrays.
+ *
+ * Return value of every function: 0 on success, a hipError_t (> 0) for HIP failures,
+ * a negative GCN_E_* for argument errors.  gcn_last_error() gives a message.
+ */
+#ifndef GCN_SPMM_H
+#define GCN_SPMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCN_E_BADARG   (-1)   /* null pointer / negative size / inconsistent plan            */
+#define GCN_E_ALIGN    (-2)   /* (reserved) alignment the selected kernel cannot handle       */
+#define GCN_E_WORKSPACE (-3)  /* workspace smaller than gcn_spmm_workspace_bytes()            */
+#define GCN_E_CAPACITY (-4)   /* planner output arrays too small                              */
+
+#define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
+#define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
+
+#define GCN_ABI_VERSION 1
+
+/*
+ * A CSR adjacency (or its transpose) plus the static launch schedule built for it once.
+ * All pointers are DEVICE pointers.  The schedule splits the rows of the matrix into
+ *   - row-batch items : runs of <= 64 consecutive "short" rows whose stored entries are
+ *                       contiguous; one wavefront streams one item;
+ *   - long rows       : rows with more than `long_thresh` stored entries, cut into chunks of
+ *                       `long_thresh` entries that are summed by separate wavefronts into a
+ *                       partial slab and then added in chunk order (bitwise reproducible;
+ *                       no float atomics).
+ * Replaces: the torch sparse tensor `adj` the reference builds at pygcn/utils.py:407-414 and
+ * passes to GraphConvolution.forward (pygcn/layers.py:32).
+ */
+typedef struct gcn_csr_plan {
+    int64_t n_rows;
+    int64_t n_cols;
+    int64_t nnz;
+    const void *rowptr;        /* [n_rows+1] int32 or int64                                  */
+    int32_t rowptr_is64;
+    int32_t long_thresh;       /* chunk length L for long rows                               */
+    const int32_t *col;        /* [nnz] column index of every stored entry                   */
+    const float *val;          /* [nnz] fp32 value of every stored entry                     */
+    int64_t n_items;
+    const int32_t *items;      /* [2*n_items] (first_row, end_row) per row-batch item        */
+    int64_t n_chunks;
+    const int32_t *chunk_row;  /* [n_chunks] row every chunk belongs to                      */
+    const int64_t *chunk_e0;   /* [n_chunks] first stored entry of the chunk                 */
+    int64_t n_long;
+    const int32_t *long_row;   /* [n_long] row index of every long row                       */
+    const int32_t *long_chunk0;/* [n_long+1] first chunk of every long row                   */
+} gcn_csr_plan;
+
+/* ABI version of the loaded library (GCN_ABI_VERSION). */
+int gcn_abi_version(void);
+
+/* Message for the last non-zero return on this thread. */
+const char *gcn_last_error(void);
+
+/*
+ * Planner, pass 1: count items / chunks / long rows for a HOST rowptr.
+ *   item_cost   : target work per row-batch item, in units of (stored entries + rows); <= 0
+ *                 selects the default (64).
+ *   long_thresh : rows with more stored entries than this are chunked; <= 0 selects the
+ *                 default (256).
+ */
+int gcn_plan_count_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
+                        int32_t item_cost, int32_t long_thresh, int64_t *n_items,
+                        int64_t *n_chunks, int64_t *n_long);
+
+/*
+ * Planner, pass 2: fill caller-allocated HOST arrays (sizes from pass 1):
+ *   items[2*n_items], chunk_row[n_chunks], chunk_e0[n_chunks], long_row[n_long],
+ *   long_chunk0[n_long+1].  The caller copies them to the device and points a gcn_csr_plan
+ *   at the copies.
+ */
+int gcn_plan_fill_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
+                       int32_t item_cost, int32_t long_thresh, int32_t *items, int64_t n_items,
+                       int32_t *chunk_row, int64_t *chunk_e0, int64_t n_chunks,
+                       int32_t *long_row, int32_t *long_chunk0, int64_t n_long);
+
+/* Bytes of DEVICE scratch gcn_spmm_csr() needs for feature width F (0 if no long rows). */
+size_t gcn_spmm_workspace_bytes(const gcn_csr_plan *plan, int64_t F);
+
+/*
+ * C[n_rows, F] = A · B  (+ bias[F], then ReLU, both optional) on `stream`.
+ *
+ *   plan       : the CSR matrix A [n_rows, n_cols] and its schedule.
+ *   dtype      : GCN_DTYPE_F32 or GCN_DTYPE_BF16 (element type of B and C).
+ *   B          : DEVICE [n_cols, F] row-major with leading dimension ldb (elements).
+ *   C          : DEVICE [n_rows, F] row-major with leading dimension ldc (elements);
+ *                every row is written (rows without stored entries become bias / zero).
+ *   bias       : DEVICE fp32 [F] or NULL                      — pygcn/layers.py:35-36.
+ *   relu       : non-zero applies max(x, 0) after the bias    — pygcn/models.py:48 (upstream).
+ *   workspace  : DEVICE scratch of at least gcn_spmm_workspace_bytes(plan, F) bytes
+ *                (may be NULL when that is 0).
+ *
+ * Forward of pygcn/layers.py:34 when `plan` describes adj; the backward product
+ * adj.t() @ grad_output when `plan` describes CSR(adj^T) (see gcn_csr_transpose_*).
+ */
+int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
+                 int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
+                 size_t workspace_bytes, void *stream);
+
+/*
+ * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of
+ * A^T lists its entries in increasing source-row order (deterministic backward sums).
+ * rowptr_t[n_cols+1] has the width of rowptr; col_t[nnz]; val_t[nnz].
+ */
+int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,
+                           const float *val, int64_t n_rows, int64_t n_cols, void *rowptr_t,
+                           int32_t *col_t, float *val_t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCN_SPMM_H */

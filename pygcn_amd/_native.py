@@ -1,0 +1,91 @@
+"""ctypes binding of the C-ABI in include/gcn_spmm.h (pygcn_amd/csrc/libgcn_spmm.so).
+
+There is NO fallback: if the HIP library is missing or does not load, every product call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
+
+GCN_ABI_VERSION = 1
+GCN_DTYPE_F32 = 0
+GCN_DTYPE_BF16 = 1
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+class GcnCsrPlan(ctypes.Structure):
+    """Mirror of `struct gcn_csr_plan` (include/gcn_spmm.h).  Pointers are device addresses."""
+    _fields_ = [
+        ("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64),
+        ("rowptr", ctypes.c_void_p), ("rowptr_is64", ctypes.c_int32),
+        ("long_thresh", ctypes.c_int32),
+        ("col", ctypes.c_void_p), ("val", ctypes.c_void_p),
+        ("n_items", ctypes.c_int64), ("items", ctypes.c_void_p),
+        ("n_chunks", ctypes.c_int64), ("chunk_row", ctypes.c_void_p),
+        ("chunk_e0", ctypes.c_void_p),
+        ("n_long", ctypes.c_int64), ("long_row", ctypes.c_void_p),
+        ("long_chunk0", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
+EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan_fill_host",
+           "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_csr_transpose_host")
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m pygcn_amd.build` "
+            "(hipcc --offload-arch=gfx950). pygcn_amd has no CPU or PyTorch fallback.")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:   # e.g. libamdhip64 not found
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    L.gcn_abi_version.restype = ctypes.c_int
+    L.gcn_last_error.restype = ctypes.c_char_p
+    L.gcn_plan_count_host.restype = ctypes.c_int
+    L.gcn_plan_count_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                      ctypes.c_int32, ctypes.c_int32, c_i64p, c_i64p, c_i64p]
+    L.gcn_plan_fill_host.restype = ctypes.c_int
+    L.gcn_plan_fill_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                     ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    L.gcn_spmm_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_spmm_workspace_bytes.argtypes = [ctypes.POINTER(GcnCsrPlan), ctypes.c_int64]
+    L.gcn_spmm_csr.restype = ctypes.c_int
+    L.gcn_spmm_csr.argtypes = [ctypes.POINTER(GcnCsrPlan), ctypes.c_int, ctypes.c_void_p,
+                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                               ctypes.c_void_p]
+    L.gcn_csr_transpose_host.restype = ctypes.c_int
+    L.gcn_csr_transpose_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    if L.gcn_abi_version() != GCN_ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
+                                 f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    """Non-zero C-ABI return -> RuntimeError (PyTorch's convention for the ops it replaces)."""
+    if rc != 0:
+        msg = lib().gcn_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,39 @@
+"""Builds pygcn_amd/csrc/libgcn_spmm.so (the C-ABI of include/gcn_spmm.h) for gfx950 with hipcc.
+
+The library is built IN-TREE so that it travels with a snapshot of the repository; hipcc
+cross-compiles without a GPU.  `python -m pygcn_amd.build` or `__graft_entry__.build()`.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "gcn_spmm.hip")
+OUT = os.path.join(HERE, "csrc", "libgcn_spmm.so")
+ARCH = "gfx950"
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    deps = [SRC, os.path.join(ROOT, "include", "gcn_spmm.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
+           "-I", os.path.join(ROOT, "include"), "-o", OUT + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

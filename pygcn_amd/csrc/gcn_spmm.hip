@@ -1,0 +1,699 @@
+// gcn_spmm.hip — CSR SpMM for the GraphConvolution hot path, written for gfx950 (MI355X, CDNA4).
+//
+// Implements the C-ABI of include/gcn_spmm.h.  What it replaces in the reference:
+//   torch.spmm(adj, support)          pygcn/layers.py:34      -> gcn_spmm_csr on CSR(adj)
+//   adj.t() @ grad_output (autograd)  pygcn/train.py:157      -> gcn_spmm_csr on CSR(adj^T)
+//   output + self.bias                pygcn/layers.py:35-36   -> fused epilogue
+//
+// Execution model (see DESIGN.md §3 for the numbers):
+//   * HBM-bound gather: every stored entry pulls one dense row B[col,:] (F*s bytes).  A 64-lane
+//     wavefront reads one such row with ONE instruction (16 B per lane -> 1 KiB for fp32 F=256),
+//     so all B traffic is full-line coalesced and the column index / value are wave-uniform
+//     scalars (v_readlane from a 64-entry register tile, scalar address arithmetic).
+//   * Latency is hidden by keeping D row-loads in flight per wave in a register ring that is
+//     refilled as soon as a slot is consumed, times 8 waves per SIMD.
+//   * Load balance on power-law graphs comes from the static schedule in gcn_csr_plan: short
+//     rows are packed into equal-cost row-batch items (one wave each); rows longer than
+//     long_thresh are cut into chunks summed by separate waves into an fp32 slab and added in
+//     chunk order by a tiny second kernel — no float atomics, bitwise reproducible.
+//   * Narrow feature widths (F*s < 1 KiB) put several stored entries of one row side by side in
+//     one wave instruction (lane groups) and finish with a wavefront shuffle reduction.
+//
+// gfx950 only.  No other architecture is supported or intended.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "gcn_spmm.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kDefaultItemCost = 64;
+constexpr int kDefaultLongThresh = 256;
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg)
+{
+    std::snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *where)
+{
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return (int)e;
+}
+
+struct KParams {
+    const void *rowptr;
+    const int32_t *col;
+    const float *val;
+    const int32_t *items;
+    const int32_t *chunk_row;
+    const int64_t *chunk_e0;
+    const int32_t *long_row;
+    const int32_t *long_chunk0;
+    const void *B;
+    void *C;
+    const float *bias;
+    float *partial;
+    int64_t ldb;   // elements
+    int64_t ldc;   // elements
+    int32_t F;
+    int32_t n_total;    // n_chunks + n_items
+    int32_t n_chunks;
+    int32_t n_long;
+    int32_t long_thresh;
+    int32_t relu;
+};
+
+// ------------------------------------------------------------------------------------------
+// element traits: how VEC elements of T travel between memory and fp32 registers
+// ------------------------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <typename T, int VEC> struct Elem;
+
+template <> struct Elem<float, 4> {
+    typedef f32x4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&x)[4])
+    {
+        x[0] = r.x; x[1] = r.y; x[2] = r.z; x[3] = r.w;
+    }
+    static __device__ __forceinline__ Raw pack(const float (&x)[4])
+    {
+        Raw r = {x[0], x[1], x[2], x[3]};
+        return r;
+    }
+};
+template <> struct Elem<float, 1> {
+    typedef float Raw;
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&x)[1]) { x[0] = r; }
+    static __device__ __forceinline__ Raw pack(const float (&x)[1]) { return x[0]; }
+};
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    f32x2 v = {lo, hi};
+    bf16x2 b = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return __builtin_bit_cast(uint32_t, b);
+}
+template <> struct Elem<bf16_t, 8> {
+    typedef u32x4 Raw;
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&x)[8])
+    {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[2 * i] = __uint_as_float(w[i] << 16);
+            x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ Raw pack(const float (&x)[8])
+    {
+        Raw r = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
+                 pack_bf16x2(x[6], x[7])};
+        return r;
+    }
+};
+template <> struct Elem<bf16_t, 1> {
+    typedef bf16_t Raw;
+    static __device__ __forceinline__ void unpack(const Raw &r, float (&x)[1])
+    {
+        x[0] = __uint_as_float(((uint32_t)r) << 16);
+    }
+    static __device__ __forceinline__ Raw pack(const float (&x)[1])
+    {
+        return (bf16_t)(pack_bf16x2(x[0], 0.f) & 0xffffu);
+    }
+};
+
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// bias add + ReLU + conversion + store of one output row segment held as VEC floats per lane
+template <typename T, int VEC>
+__device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
+                                          const float (&acc)[VEC], const float (&bias)[VEC])
+{
+    float o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        o[i] = acc[i] + bias[i];
+        if (p.relu) o[i] = fmaxf(o[i], 0.f);
+    }
+    if (act) {
+        T *dst = (T *)p.C + row * p.ldc + f;
+        *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// WIDE kernel: one dense row segment (64 lanes x VEC elements) per wave instruction.
+// Used when F/VEC > 32 lanes; blockIdx.y walks further 64*VEC-wide feature slabs.
+// ------------------------------------------------------------------------------------------
+// 16-byte load of a dense-row segment through a buffer descriptor built from wave-uniform
+// scalars: base = B + col*ldb (SGPR pair), num_records = row bytes.  The hardware range check
+// returns zeros for lanes past the end of the row (feature tail) and for whole slots whose
+// num_records is 0 (slots past the end of an edge tile), so the gather needs no branches.
+__device__ __forceinline__ u32x4 row_load16(uint64_t base, uint32_t nbytes, uint32_t voff)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    void *pb = (void *)(((uint64_t)hi << 32) | lo);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pb, 0, nbytes, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+}
+
+template <typename T, int VEC, int D, bool ROWS>
+__device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__restrict__ colp,
+                                            const float *__restrict__ valp, int ne, int lane,
+                                            unsigned ld_off_bytes, float (&acc)[VEC],
+                                            int rel_end, int nr, int64_t row0, int f, bool act,
+                                            const float (&bias)[VEC])
+{
+    typedef typename Elem<T, VEC>::Raw Raw;
+    static_assert(sizeof(Raw) == 16, "wide kernel moves 16 bytes per lane");
+    const uint32_t ldb_bytes = (uint32_t)(p.ldb * (int64_t)sizeof(T));   // < 4 GiB, host-checked
+    const uint32_t row_bytes = (uint32_t)p.F * (uint32_t)sizeof(T);
+    int r = 0;
+    int rend = ROWS ? readlane_i(rel_end, 0) : INT_MAX;
+
+    auto consume = [&](int e, const u32x4 &raw, float a) {
+        if (ROWS) {
+            while (e >= rend) {   // row finished (loop: rows without stored entries follow)
+                store_out<T, VEC>(p, row0 + r, f, act, acc, bias);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+                ++r;
+                rend = readlane_i(rel_end, r);
+            }
+        }
+        float x[VEC];
+        Elem<T, VEC>::unpack(__builtin_bit_cast(Raw, raw), x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a, x[i], acc[i]);
+    };
+
+    for (int t = 0; t < ne; t += kWave) {
+        const int cnt = min(kWave, ne - t);
+        int cv = 0;
+        float vv = 0.f;   // lanes >= cnt keep value 0: slots past the tile add 0 * 0
+        if (lane < cnt) {
+            cv = colp[t + lane];
+            vv = valp[t + lane];
+        }
+        for (int k = 0; k < cnt; k += D) {
+            // D row loads in flight, branch-free
+            u32x4 x[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const bool ok = k + j < cnt;
+                const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
+                x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
+                                  ok ? row_bytes : 0u, ld_off_bytes);
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                consume(min(t + k + j, ne - 1), x[j], readlane_f(vv, k + j));
+        }
+    }
+    if (ROWS) {
+        while (r < nr) {   // last row of the item and any trailing empty rows
+            store_out<T, VEC>(p, row0 + r, f, act, acc, bias);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            ++r;
+        }
+    }
+}
+
+template <typename T, int VEC, typename IdxT, int D>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParams p)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item =
+        blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= p.n_total) return;
+    const int f = blockIdx.y * (kWave * VEC) + lane * VEC;
+    const bool act = f < p.F;
+    // lanes past the end of the row (F not a multiple of 64*VEC) are zeroed by the range check
+    const unsigned ld_off_bytes = (unsigned)f * (unsigned)sizeof(T);
+    const IdxT *__restrict__ rp = (const IdxT *)p.rowptr;
+
+    float acc[VEC], bias[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        acc[i] = 0.f;
+        bias[i] = 0.f;
+    }
+
+    if (item < p.n_chunks) {
+        // ---- one chunk of a long row -> fp32 partial slab
+        const int row = p.chunk_row[item];
+        const int64_t e0 = p.chunk_e0[item];
+        const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
+        wide_stream<T, VEC, D, false>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
+                                      ld_off_bytes, acc, 0, 0, 0, f, act, bias);
+        if (act) {
+            float *dst = p.partial + (int64_t)item * p.F + f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dst[i] = acc[i];
+        }
+        return;
+    }
+
+    // ---- a row-batch item: rows [ra, rb), <= 64 rows, contiguous stored entries
+    const int it = item - p.n_chunks;
+    const int ra = p.items[2 * it], rb = p.items[2 * it + 1];
+    const int nr = rb - ra;
+    const int64_t ea = (int64_t)rp[ra];
+    const int rel_end = (lane < nr) ? (int)((int64_t)rp[ra + 1 + lane] - ea) : 0;
+    const int ne = readlane_i(rel_end, nr - 1);
+    if (p.bias != nullptr && act) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
+    }
+    wide_stream<T, VEC, D, true>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
+                                 nr, (int64_t)ra, f, act, bias);
+}
+
+// ------------------------------------------------------------------------------------------
+// NARROW kernel: a dense row segment needs only LPR (< 64, or 64 with scalar elements) lanes,
+// so G = 64/LPR stored entries of the SAME output row travel side by side in one wave
+// instruction; the G partial sums meet in a wavefront shuffle reduction.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR, int U>
+__device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__restrict__ col,
+                                           const float *__restrict__ val, int64_t e0, int64_t e1,
+                                           int g, unsigned ld_off, float (&acc)[VEC])
+{
+    typedef typename Elem<T, VEC>::Raw Raw;
+    constexpr int G = kWave / LPR;
+    const int64_t ldb_bytes = p.ldb * (int64_t)sizeof(T);
+    for (int64_t e = e0; e < e1; e += (int64_t)G * U) {   // uniform trip count
+        int c[U];
+        float a[U];
+        Raw x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ee = e + (int64_t)u * G + g;
+            const bool ok = ee < e1;
+            c[u] = ok ? col[ee] : 0;
+            a[u] = ok ? val[ee] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // masked-off entries re-read row 0 with weight 0 only if row 0 is finite; avoid the
+            // multiply instead: load from the entry's own clamp (col 0) but zero the raw value.
+            x[u] = *(const Raw *)((const char *)p.B + (int64_t)c[u] * ldb_bytes + ld_off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t ee = e + (int64_t)u * G + g;
+            if (ee < e1) {
+                float xf[VEC];
+                Elem<T, VEC>::unpack(x[u], xf);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] = fmaf(a[u], xf[i], acc[i]);
+            }
+        }
+    }
+    if (G > 1) {
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
+        }
+    }
+}
+
+template <typename T, int VEC, int LPR, typename IdxT>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KParams p)
+{
+    constexpr int U = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item =
+        blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= p.n_total) return;
+    const int g = lane / LPR, l = lane % LPR;
+    const int f = blockIdx.y * (LPR * VEC) + l * VEC;
+    const bool act = f < p.F;
+    const unsigned ld_off = act ? (unsigned)f * (unsigned)sizeof(T) : 0u;
+    const IdxT *__restrict__ rp = (const IdxT *)p.rowptr;
+
+    float acc[VEC], bias[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        acc[i] = 0.f;
+        bias[i] = 0.f;
+    }
+
+    if (item < p.n_chunks) {
+        const int row = p.chunk_row[item];
+        const int64_t e0 = p.chunk_e0[item];
+        const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
+        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
+        if (act && g == 0) {
+            float *dst = p.partial + (int64_t)item * p.F + f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dst[i] = acc[i];
+        }
+        return;
+    }
+
+    const int it = item - p.n_chunks;
+    const int ra = p.items[2 * it], rb = p.items[2 * it + 1];
+    if (p.bias != nullptr && act) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
+    }
+    int64_t e0 = (int64_t)rp[ra];
+    for (int r = ra; r < rb; ++r) {
+        const int64_t e1 = (int64_t)rp[r + 1];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
+        store_out<T, VEC>(p, (int64_t)r, f, act && g == 0, acc, bias);
+        e0 = e1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// long rows: add the chunk partials in chunk order, apply the epilogue, write the row
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
+{
+    const int j = blockIdx.x;
+    if (j >= p.n_long) return;
+    const int64_t row = p.long_row[j];
+    const int c0 = p.long_chunk0[j], c1 = p.long_chunk0[j + 1];
+    for (int f = threadIdx.x; f < p.F; f += blockDim.x) {
+        float s = 0.f;
+        for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
+        float a[1] = {s};
+        float b[1] = {p.bias ? p.bias[f] : 0.f};
+        store_out<T, 1>(p, row, f, true, a, b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR>
+void launch_narrow(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
+{
+    if (is64)
+        hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, int64_t>), grid,
+                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+    else
+        hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, int32_t>), grid,
+                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+}
+
+template <typename T, int VEC>
+void launch_narrow_lpr(const KParams &kp, bool is64, int lpr, dim3 grid, hipStream_t s)
+{
+    switch (lpr) {
+    case 1: launch_narrow<T, VEC, 1>(kp, is64, grid, s); break;
+    case 2: launch_narrow<T, VEC, 2>(kp, is64, grid, s); break;
+    case 4: launch_narrow<T, VEC, 4>(kp, is64, grid, s); break;
+    case 8: launch_narrow<T, VEC, 8>(kp, is64, grid, s); break;
+    case 16: launch_narrow<T, VEC, 16>(kp, is64, grid, s); break;
+    case 32: launch_narrow<T, VEC, 32>(kp, is64, grid, s); break;
+    default: launch_narrow<T, VEC, 64>(kp, is64, grid, s); break;
+    }
+}
+
+template <typename T, int VEC>
+void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
+{
+    constexpr int D = 8;
+    if (is64)
+        hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D>), grid,
+                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+    else
+        hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D>), grid,
+                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+}
+
+int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+template <typename T, int VECW>
+int spmm_typed(const gcn_csr_plan *plan, KParams &kp, hipStream_t s)
+{
+    const int F = kp.F;
+    const bool is64 = plan->rowptr_is64 != 0;
+    const bool vec_ok = (F % VECW == 0) && (((uintptr_t)kp.B) % 16 == 0) &&
+                        (((uintptr_t)kp.C) % 16 == 0) &&
+                        ((kp.ldb * (int64_t)sizeof(T)) % 16 == 0) &&
+                        ((kp.ldc * (int64_t)sizeof(T)) % 16 == 0);
+    const unsigned nblk = (unsigned)((kp.n_total + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (kp.n_total > 0) {
+        if (vec_ok) {
+            const int lanes = F / VECW;
+            if (lanes > 32) {
+                dim3 grid(nblk, (unsigned)((lanes + kWave - 1) / kWave));
+                launch_wide<T, VECW>(kp, is64, grid, s);
+            } else {
+                dim3 grid(nblk, 1);
+                launch_narrow_lpr<T, VECW>(kp, is64, next_pow2(lanes), grid, s);
+            }
+        } else {
+            const int lpr = std::min(kWave, next_pow2(F));
+            dim3 grid(nblk, (unsigned)((F + lpr - 1) / lpr));
+            launch_narrow_lpr<T, 1>(kp, is64, lpr, grid, s);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "spmm launch");
+    }
+    if (kp.n_long > 0) {
+        hipLaunchKernelGGL((spmm_long_reduce_kernel<T>), dim3((unsigned)kp.n_long), dim3(256), 0,
+                           s, kp);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "long-row reduce launch");
+    }
+    return 0;
+}
+
+template <typename IdxT>
+int plan_walk(const IdxT *rp, int64_t n_rows, int item_cost, int long_thresh, int32_t *items,
+              int64_t cap_items, int32_t *chunk_row, int64_t *chunk_e0, int64_t cap_chunks,
+              int32_t *long_row, int32_t *long_chunk0, int64_t cap_long, int64_t *n_items,
+              int64_t *n_chunks, int64_t *n_long)
+{
+    const bool fill = items != nullptr;
+    int64_t ni = 0, nc = 0, nl = 0;
+    int64_t ra = 0, cost = 0;
+    auto close = [&](int64_t rb) -> bool {
+        if (rb > ra) {
+            if (fill) {
+                if (ni >= cap_items) return false;
+                items[2 * ni] = (int32_t)ra;
+                items[2 * ni + 1] = (int32_t)rb;
+            }
+            ++ni;
+        }
+        ra = rb;
+        cost = 0;
+        return true;
+    };
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t deg = (int64_t)rp[r + 1] - (int64_t)rp[r];
+        if (deg < 0) return GCN_E_BADARG;
+        if (deg > long_thresh) {
+            if (!close(r)) return GCN_E_CAPACITY;
+            ra = r + 1;   // the long row belongs to no row-batch item
+            const int64_t k = (deg + long_thresh - 1) / long_thresh;
+            if (fill) {
+                if (nl >= cap_long || nc + k > cap_chunks) return GCN_E_CAPACITY;
+                long_row[nl] = (int32_t)r;
+                long_chunk0[nl] = (int32_t)nc;
+                for (int64_t c = 0; c < k; ++c) {
+                    chunk_row[nc + c] = (int32_t)r;
+                    chunk_e0[nc + c] = (int64_t)rp[r] + c * long_thresh;
+                }
+            }
+            nc += k;
+            ++nl;
+            continue;
+        }
+        const int64_t c = deg + 1;
+        if (r > ra && (cost + c > item_cost || r - ra >= kWave)) {
+            if (!close(r)) return GCN_E_CAPACITY;
+        }
+        cost += c;
+    }
+    if (!close(n_rows)) return GCN_E_CAPACITY;
+    if (fill && long_chunk0 != nullptr) {
+        if (nl > cap_long) return GCN_E_CAPACITY;
+        long_chunk0[nl] = (int32_t)nc;
+    }
+    if (n_items) *n_items = ni;
+    if (n_chunks) *n_chunks = nc;
+    if (n_long) *n_long = nl;
+    return 0;
+}
+
+}   // namespace
+
+extern "C" {
+
+int gcn_abi_version(void) { return GCN_ABI_VERSION; }
+
+const char *gcn_last_error(void) { return g_err; }
+
+int gcn_plan_count_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
+                        int32_t item_cost, int32_t long_thresh, int64_t *n_items,
+                        int64_t *n_chunks, int64_t *n_long)
+{
+    if (rowptr_host == nullptr || n_rows < 0 || n_rows >= INT32_MAX)
+        return fail(GCN_E_BADARG, "gcn_plan_count_host: bad rowptr / n_rows");
+    if (item_cost <= 0) item_cost = kDefaultItemCost;
+    if (long_thresh <= 0) long_thresh = kDefaultLongThresh;
+    int rc = rowptr_is64
+                 ? plan_walk((const int64_t *)rowptr_host, n_rows, item_cost, long_thresh, nullptr,
+                             0, nullptr, nullptr, 0, nullptr, nullptr, 0, n_items, n_chunks, n_long)
+                 : plan_walk((const int32_t *)rowptr_host, n_rows, item_cost, long_thresh, nullptr,
+                             0, nullptr, nullptr, 0, nullptr, nullptr, 0, n_items, n_chunks,
+                             n_long);
+    return rc ? fail(rc, "gcn_plan_count_host: rowptr is not monotone") : 0;
+}
+
+int gcn_plan_fill_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
+                       int32_t item_cost, int32_t long_thresh, int32_t *items, int64_t n_items,
+                       int32_t *chunk_row, int64_t *chunk_e0, int64_t n_chunks,
+                       int32_t *long_row, int32_t *long_chunk0, int64_t n_long)
+{
+    if (rowptr_host == nullptr || n_rows < 0 || n_rows >= INT32_MAX || items == nullptr ||
+        long_chunk0 == nullptr)
+        return fail(GCN_E_BADARG, "gcn_plan_fill_host: null output or bad n_rows");
+    if (item_cost <= 0) item_cost = kDefaultItemCost;
+    if (long_thresh <= 0) long_thresh = kDefaultLongThresh;
+    int64_t ni = 0, nc = 0, nl = 0;
+    int rc = rowptr_is64 ? plan_walk((const int64_t *)rowptr_host, n_rows, item_cost, long_thresh,
+                                     items, n_items, chunk_row, chunk_e0, n_chunks, long_row,
+                                     long_chunk0, n_long, &ni, &nc, &nl)
+                         : plan_walk((const int32_t *)rowptr_host, n_rows, item_cost, long_thresh,
+                                     items, n_items, chunk_row, chunk_e0, n_chunks, long_row,
+                                     long_chunk0, n_long, &ni, &nc, &nl);
+    if (rc) return fail(rc, "gcn_plan_fill_host: output arrays too small or rowptr not monotone");
+    if (ni != n_items || nc != n_chunks || nl != n_long)
+        return fail(GCN_E_CAPACITY, "gcn_plan_fill_host: sizes differ from gcn_plan_count_host");
+    return 0;
+}
+
+size_t gcn_spmm_workspace_bytes(const gcn_csr_plan *plan, int64_t F)
+{
+    if (plan == nullptr || F <= 0 || plan->n_chunks <= 0) return 0;
+    return (size_t)plan->n_chunks * (size_t)F * sizeof(float);
+}
+
+int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
+                 int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    if (plan == nullptr) return fail(GCN_E_BADARG, "gcn_spmm_csr: plan is NULL");
+    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: unknown dtype");
+    if (plan->n_rows < 0 || plan->n_cols < 0 || plan->nnz < 0 || F < 0 || F > INT32_MAX)
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: negative size");
+    if (plan->n_rows == 0 || F == 0) return 0;
+    if (C == nullptr || (B == nullptr && plan->nnz > 0))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: B or C is NULL");
+    if (ldb < F || ldc < F) return fail(GCN_E_BADARG, "gcn_spmm_csr: ldb/ldc smaller than F");
+    if (ldb * 4 >= ((int64_t)1 << 32))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: row stride of B must be below 4 GiB");
+    if (plan->rowptr == nullptr || plan->items == nullptr ||
+        (plan->nnz > 0 && (plan->col == nullptr || plan->val == nullptr)))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: plan has NULL arrays");
+    if (plan->n_chunks > 0 && (plan->chunk_row == nullptr || plan->chunk_e0 == nullptr ||
+                               plan->long_row == nullptr || plan->long_chunk0 == nullptr))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: plan has long rows but NULL chunk arrays");
+    if (plan->n_items + plan->n_chunks >= INT32_MAX || plan->n_long >= INT32_MAX)
+        return fail(GCN_E_BADARG, "gcn_spmm_csr: schedule too large");
+    const size_t need = gcn_spmm_workspace_bytes(plan, F);
+    if (need > 0 && (workspace == nullptr || workspace_bytes < need))
+        return fail(GCN_E_WORKSPACE, "gcn_spmm_csr: workspace too small");
+
+    KParams kp;
+    kp.rowptr = plan->rowptr;
+    kp.col = plan->col;
+    kp.val = plan->val;
+    kp.items = plan->items;
+    kp.chunk_row = plan->chunk_row;
+    kp.chunk_e0 = plan->chunk_e0;
+    kp.long_row = plan->long_row;
+    kp.long_chunk0 = plan->long_chunk0;
+    kp.B = B;
+    kp.C = C;
+    kp.bias = bias;
+    kp.partial = (float *)workspace;
+    kp.ldb = ldb;
+    kp.ldc = ldc;
+    kp.F = (int32_t)F;
+    kp.n_total = (int32_t)(plan->n_items + plan->n_chunks);
+    kp.n_chunks = (int32_t)plan->n_chunks;
+    kp.n_long = (int32_t)plan->n_long;
+    kp.long_thresh = plan->long_thresh > 0 ? plan->long_thresh : kDefaultLongThresh;
+    kp.relu = relu ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GCN_DTYPE_F32) return spmm_typed<float, 4>(plan, kp, s);
+    return spmm_typed<bf16_t, 8>(plan, kp, s);
+}
+
+int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,
+                           const float *val, int64_t n_rows, int64_t n_cols, void *rowptr_t,
+                           int32_t *col_t, float *val_t)
+{
+    if (rowptr_host == nullptr || rowptr_t == nullptr || n_rows < 0 || n_cols < 0)
+        return fail(GCN_E_BADARG, "gcn_csr_transpose_host: bad arguments");
+    auto run = [&](auto *rp, auto *rpt) -> int {
+        typedef typename std::remove_pointer<decltype(rpt)>::type I;
+        const int64_t nnz = (int64_t)rp[n_rows];
+        if (nnz > 0 && (col == nullptr || val == nullptr || col_t == nullptr || val_t == nullptr))
+            return GCN_E_BADARG;
+        for (int64_t k = 0; k <= n_cols; ++k) rpt[k] = 0;
+        for (int64_t e = 0; e < nnz; ++e) {
+            if (col[e] < 0 || col[e] >= n_cols) return GCN_E_BADARG;
+            rpt[col[e] + 1]++;
+        }
+        for (int64_t k = 0; k < n_cols; ++k) rpt[k + 1] += rpt[k];
+        for (int64_t i = 0; i < n_rows; ++i) {
+            for (int64_t e = (int64_t)rp[i]; e < (int64_t)rp[i + 1]; ++e) {
+                const int64_t dst = (int64_t)rpt[col[e]]++;
+                col_t[dst] = (int32_t)i;
+                val_t[dst] = val[e];
+            }
+        }
+        for (int64_t k = n_cols; k > 0; --k) rpt[k] = rpt[k - 1];
+        rpt[0] = (I)0;
+        return 0;
+    };
+    int rc = rowptr_is64 ? run((const int64_t *)rowptr_host, (int64_t *)rowptr_t)
+                         : run((const int32_t *)rowptr_host, (int32_t *)rowptr_t);
+    return rc ? fail(rc, "gcn_csr_transpose_host: column index out of range or NULL array") : 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,212 @@
+"""CSRGraph — the prepared adjacency handle of the MI355X GraphConvolution path.
+
+Replaces the torch sparse COO tensor the reference builds once at load time
+(`sparse_mx_to_torch_sparse_tensor`, reference pygcn/utils.py:407-414) and passes to every
+`GraphConvolution.forward(input, adj)` (pygcn/layers.py:32).  The handle owns, in HBM:
+
+  * CSR(A): rowptr (int32, or int64 when nnz >= 2^31), col (int32), val (fp32);
+  * the static launch schedule for it (`struct gcn_csr_plan`, include/gcn_spmm.h), built once by
+    the native planner from the row lengths;
+  * lazily, the same for CSR(A^T), which the backward product A^T·grad needs
+    (reference: autograd of `torch.spmm`, pygcn/train.py:157).  The reference (PyTorch) re-derives
+    the transpose on every backward call; here it is built once and cached.
+
+Conversions from torch / scipy layouts are one-off host+device plumbing done with torch ops.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"pygcn_amd: {what} must live on a HIP device (got {t.device}). The MI355X path has "
+            "no CPU implementation; move the tensor with .cuda().")
+
+
+class CSRGraph:
+    """Sparse matrix A [n_rows, n_cols] in CSR on a HIP device, with its launch schedule."""
+
+    def __init__(self, rowptr, col, val, shape, item_cost=0, long_thresh=0):
+        for name, t in (("rowptr", rowptr), ("col", col), ("val", val)):
+            _require_cuda(t, name)
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if rowptr.dtype not in (torch.int32, torch.int64) or rowptr.numel() != n_rows + 1:
+            raise RuntimeError("rowptr must be int32/int64 with n_rows+1 entries")
+        if col.dtype != torch.int32 or val.dtype != torch.float32 or col.numel() != val.numel():
+            raise RuntimeError("col must be int32 and val float32, same length")
+        self.rowptr = rowptr.contiguous()
+        self.col = col.contiguous()
+        self.val = val.contiguous()
+        self.shape = (n_rows, n_cols)
+        self.nnz = int(col.numel())
+        self.device = val.device
+        self.item_cost = int(item_cost)
+        self.long_thresh = int(long_thresh)
+        self._plan = None
+        self._keep = None
+        self._t = None
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_coo(cls, row, col, val, shape, device=None, coalesced=False, **kw):
+        """COO triplets (any order, duplicates allowed — torch.spmm sums them) -> CSR."""
+        row = torch.as_tensor(row)
+        device = torch.device(device) if device is not None else row.device
+        row = row.to(device=device, dtype=torch.int64)
+        col = torch.as_tensor(col).to(device=device, dtype=torch.int64)
+        val = torch.as_tensor(val).to(device=device, dtype=torch.float32)
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        if row.numel() and (int(row.max()) >= n_rows or int(col.max()) >= n_cols or
+                            int(row.min()) < 0 or int(col.min()) < 0):
+            raise RuntimeError("COO index out of range for the given shape")
+        if not coalesced and row.numel():
+            key = row * n_cols + col
+            key, perm = torch.sort(key, stable=True)
+            uniq, inv = torch.unique_consecutive(key, return_inverse=True)
+            if uniq.numel() != key.numel():   # sum duplicates in storage order
+                val = torch.zeros(uniq.numel(), dtype=torch.float32, device=device).index_add_(
+                    0, inv, val[perm])
+            else:
+                val = val[perm]
+            row, col = uniq // n_cols, uniq % n_cols
+        counts = torch.bincount(row, minlength=n_rows) if row.numel() else torch.zeros(
+            n_rows, dtype=torch.int64, device=device)
+        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        if row.numel() < 2 ** 31 - 1:
+            rowptr = rowptr.to(torch.int32)
+        return cls(rowptr, col.to(torch.int32), val, (n_rows, n_cols), **kw)
+
+    @classmethod
+    def from_torch(cls, adj, device=None, **kw):
+        """torch sparse COO (the reference's layout, utils.py:414) or sparse CSR tensor."""
+        device = torch.device(device) if device is not None else adj.device
+        if adj.layout == torch.sparse_coo:
+            idx, val = adj._indices(), adj._values()
+            return cls.from_coo(idx[0], idx[1], val, adj.shape, device=device,
+                                coalesced=False, **kw)
+        if adj.layout == torch.sparse_csr:
+            rowptr = adj.crow_indices().to(device)
+            if adj._nnz() < 2 ** 31 - 1:
+                rowptr = rowptr.to(torch.int32)
+            return cls(rowptr, adj.col_indices().to(device=device, dtype=torch.int32),
+                       adj.values().to(device=device, dtype=torch.float32), adj.shape, **kw)
+        raise RuntimeError(f"unsupported adjacency layout {adj.layout}")
+
+    @classmethod
+    def from_scipy(cls, m, device="cuda", **kw):
+        import scipy.sparse as sp
+        m = sp.csr_matrix(m)
+        m.sum_duplicates()
+        m.sort_indices()
+        rp_dtype = np.int32 if m.nnz < 2 ** 31 - 1 else np.int64
+        return cls(torch.from_numpy(m.indptr.astype(rp_dtype)).to(device),
+                   torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                   torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape, **kw)
+
+    # ------------------------------------------------------------------ schedule
+    def plan(self):
+        """`struct gcn_csr_plan` for this matrix (built once, cached)."""
+        if self._plan is not None:
+            return self._plan
+        L = _native.lib()
+        rp_host = self.rowptr.cpu().numpy()
+        is64 = int(self.rowptr.dtype == torch.int64)
+        n_rows = self.shape[0]
+        ni, nc, nl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _native.check(L.gcn_plan_count_host(rp_host.ctypes.data, is64, n_rows, self.item_cost,
+                                            self.long_thresh, ctypes.byref(ni), ctypes.byref(nc),
+                                            ctypes.byref(nl)), "gcn_plan_count_host")
+        ni, nc, nl = ni.value, nc.value, nl.value
+        items = np.empty(max(2 * ni, 1), np.int32)
+        chunk_row = np.empty(max(nc, 1), np.int32)
+        chunk_e0 = np.empty(max(nc, 1), np.int64)
+        long_row = np.empty(max(nl, 1), np.int32)
+        long_chunk0 = np.empty(nl + 1, np.int32)
+        _native.check(L.gcn_plan_fill_host(rp_host.ctypes.data, is64, n_rows, self.item_cost,
+                                           self.long_thresh, items.ctypes.data, ni,
+                                           chunk_row.ctypes.data, chunk_e0.ctypes.data, nc,
+                                           long_row.ctypes.data, long_chunk0.ctypes.data, nl),
+                      "gcn_plan_fill_host")
+        dev = self.device
+        keep = {k: torch.from_numpy(v).to(dev) for k, v in (
+            ("items", items), ("chunk_row", chunk_row), ("chunk_e0", chunk_e0),
+            ("long_row", long_row), ("long_chunk0", long_chunk0))}
+        p = _native.GcnCsrPlan()
+        p.n_rows, p.n_cols, p.nnz = n_rows, self.shape[1], self.nnz
+        p.rowptr, p.rowptr_is64 = self.rowptr.data_ptr(), is64
+        p.long_thresh = self.long_thresh if self.long_thresh > 0 else 256
+        p.col, p.val = self.col.data_ptr(), self.val.data_ptr()
+        p.n_items, p.items = ni, keep["items"].data_ptr()
+        p.n_chunks, p.chunk_row, p.chunk_e0 = nc, keep["chunk_row"].data_ptr(), \
+            keep["chunk_e0"].data_ptr()
+        p.n_long, p.long_row, p.long_chunk0 = nl, keep["long_row"].data_ptr(), \
+            keep["long_chunk0"].data_ptr()
+        self._keep = keep
+        self._plan = p
+        return p
+
+    def schedule_stats(self):
+        p = self.plan()
+        return {"n_items": int(p.n_items), "n_chunks": int(p.n_chunks), "n_long": int(p.n_long),
+                "long_thresh": int(p.long_thresh)}
+
+    # ------------------------------------------------------------------ transpose (for backward)
+    def t(self):
+        """CSR(A^T), built once.  Within each row of A^T the entries are in increasing source-row
+        order (stable sort by column), so backward sums are deterministic."""
+        if self._t is None:
+            n_rows, n_cols = self.shape
+            dev = self.device
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            src_row = torch.repeat_interleave(
+                torch.arange(n_rows, device=dev, dtype=torch.int32), deg)
+            _, perm = torch.sort(self.col, stable=True)
+            col_t = src_row[perm]
+            val_t = self.val[perm]
+            del perm, src_row
+            counts = torch.bincount(self.col, minlength=n_cols) if self.nnz else torch.zeros(
+                n_cols, dtype=torch.int64, device=dev)
+            rowptr_t = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=rowptr_t[1:])
+            if self.rowptr.dtype == torch.int32:
+                rowptr_t = rowptr_t.to(torch.int32)
+            g = CSRGraph(rowptr_t, col_t, val_t, (n_cols, n_rows), item_cost=self.item_cost,
+                         long_thresh=self.long_thresh)
+            g._t = self
+            self._t = g
+        return self._t
+
+    # ------------------------------------------------------------------ misc
+    def to_torch_csr(self):
+        return torch.sparse_csr_tensor(self.rowptr.to(torch.int64), self.col.to(torch.int64),
+                                       self.val, size=self.shape)
+
+    def __repr__(self):
+        return f"CSRGraph(shape={self.shape}, nnz={self.nnz}, device={self.device})"
+
+
+_ADJ_CACHE_ATTR = "_pygcn_amd_graph"
+
+
+def as_graph(adj):
+    """Accept what the reference's layer accepts for `adj` and return the prepared handle.
+    torch sparse COO/CSR tensors are converted ONCE and the handle is cached on the tensor."""
+    if isinstance(adj, CSRGraph):
+        return adj
+    if isinstance(adj, torch.Tensor) and adj.layout in (torch.sparse_coo, torch.sparse_csr):
+        g = getattr(adj, _ADJ_CACHE_ATTR, None)
+        if g is None:
+            _require_cuda(adj, "adj")
+            g = CSRGraph.from_torch(adj)
+            try:
+                setattr(adj, _ADJ_CACHE_ATTR, g)
+            except AttributeError:
+                pass
+        return g
+    raise RuntimeError(f"adj must be a CSRGraph or a torch sparse tensor, got {type(adj)}")

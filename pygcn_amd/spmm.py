@@ -1,0 +1,81 @@
+"""The sparse x dense product of the GraphConvolution layer as a HIP custom op with autograd.
+
+Replaces `torch.spmm(adj, support)` (reference pygcn/layers.py:34) and the product
+`adj.t() @ grad_output` that autograd runs for it (pygcn/train.py:157), plus — optionally fused
+into the kernel's store — `output + self.bias` (pygcn/layers.py:35-36) and the ReLU that follows
+the layer in the model (upstream form, pygcn/models.py:48).
+
+Every call goes through the C-ABI `gcn_spmm_csr` (include/gcn_spmm.h).  No CPU / PyTorch
+fallback exists: non-HIP tensors or a missing library raise.
+"""
+import torch
+
+from . import _native
+from .graph import CSRGraph, _require_cuda, as_graph
+
+_DTYPES = {torch.float32: _native.GCN_DTYPE_F32, torch.bfloat16: _native.GCN_DTYPE_BF16}
+
+
+def spmm_csr(graph, B, bias=None, relu=False, out=None):
+    """C = A · B (+ bias, ReLU) on the current HIP stream; A is a CSRGraph, B dense [n_cols, F]."""
+    if not isinstance(graph, CSRGraph):
+        raise RuntimeError("spmm_csr: graph must be a CSRGraph")
+    _require_cuda(B, "dense operand")
+    if B.dim() != 2 or B.shape[0] != graph.shape[1]:
+        raise RuntimeError(f"size mismatch, adj {graph.shape} x dense {tuple(B.shape)}")
+    if B.dtype not in _DTYPES:
+        raise RuntimeError(f"spmm_csr supports float32 and bfloat16, got {B.dtype}")
+    if B.device != graph.device:
+        raise RuntimeError(f"adj is on {graph.device} but dense operand on {B.device}")
+    if B.shape[1] > 0 and B.stride(1) != 1:
+        B = B.contiguous()
+    n_rows, F = graph.shape[0], B.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, F), dtype=B.dtype, device=B.device)
+    elif out.shape != (n_rows, F) or out.dtype != B.dtype or out.stride(1) != 1:
+        raise RuntimeError("spmm_csr: bad `out`")
+    if n_rows == 0 or F == 0:
+        return out
+    if bias is not None:
+        _require_cuda(bias, "bias")
+        bias = bias.detach().to(torch.float32).contiguous()
+        if bias.numel() != F:
+            raise RuntimeError("bias must have F entries")
+    L = _native.lib()
+    plan = graph.plan()
+    ws_bytes = L.gcn_spmm_workspace_bytes(plan, F)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=B.device) if ws_bytes else None
+    with torch.cuda.device(B.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = L.gcn_spmm_csr(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
+                            out.data_ptr(), out.stride(0), F,
+                            bias.data_ptr() if bias is not None else None, int(bool(relu)),
+                            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+    _native.check(rc, "gcn_spmm_csr")
+    return out
+
+
+class SpMMFunction(torch.autograd.Function):
+    """out = A · B [+ bias];  grad_B = A^T · grad_out;  grad_bias = column sums of grad_out.
+    `adj` never receives a gradient (it is a loaded constant in the reference: train.py:80,123).
+    Only the graph handle is kept for backward — not B."""
+
+    @staticmethod
+    def forward(ctx, graph, B, bias):
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        return spmm_csr(graph, B, bias=bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_B = grad_bias = None
+        if ctx.needs_input_grad[1]:
+            grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_out.sum(0)
+        return None, grad_B, grad_bias
+
+
+def spmm(adj, dense, bias=None):
+    """Drop-in for `torch.spmm(adj, dense)` (+ optional fused bias) with autograd."""
+    return SpMMFunction.apply(as_graph(adj), dense, bias)

@@ -1,0 +1,194 @@
+"""CPU-side tests of the product's host logic: the C-ABI library loads and exports every symbol
+of include/gcn_spmm.h, the native planner and transpose are correct, the module surface matches
+the reference's, and the product refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from conftest import ROOT, assert_normwise, load_golden
+from pygcn_amd import _native
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gcn_spmm.h")).read()
+    declared = set(re.findall(r"\b(gcn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    L = _native.lib()
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert L.gcn_abi_version() == _native.GCN_ABI_VERSION
+
+
+def test_plan_struct_layout_matches_header():
+    # 3*8 + 8 + 4 + 4 + 2*8 + (8+8) + (8+8+8) + (8+8+8) bytes, natural alignment, no padding holes
+    assert ctypes.sizeof(_native.GcnCsrPlan) == 120
+    assert _native.GcnCsrPlan.col.offset == 40 and _native.GcnCsrPlan.n_items.offset == 56
+
+
+def _plan(rowptr, item_cost=0, long_thresh=0):
+    L = _native.lib()
+    rp = np.ascontiguousarray(rowptr)
+    is64 = int(rp.dtype == np.int64)
+    n = len(rp) - 1
+    ni, nc, nl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    rc = L.gcn_plan_count_host(rp.ctypes.data, is64, n, item_cost, long_thresh,
+                               ctypes.byref(ni), ctypes.byref(nc), ctypes.byref(nl))
+    assert rc == 0
+    ni, nc, nl = ni.value, nc.value, nl.value
+    items = np.zeros(max(2 * ni, 1), np.int32)
+    crow, ce0 = np.zeros(max(nc, 1), np.int32), np.zeros(max(nc, 1), np.int64)
+    lrow, lc0 = np.zeros(max(nl, 1), np.int32), np.zeros(nl + 1, np.int32)
+    rc = L.gcn_plan_fill_host(rp.ctypes.data, is64, n, item_cost, long_thresh,
+                              items.ctypes.data, ni, crow.ctypes.data, ce0.ctypes.data, nc,
+                              lrow.ctypes.data, lc0.ctypes.data, nl)
+    assert rc == 0
+    return items[:2 * ni].reshape(-1, 2), crow[:nc], ce0[:nc], lrow[:nl], lc0
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.int64])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_planner_covers_every_row_exactly_once(dtype, seed):
+    rng = np.random.default_rng(seed)
+    n = 5000
+    deg = rng.integers(0, 12, size=n)
+    deg[rng.integers(0, n, size=20)] = rng.integers(257, 3000, size=20)   # long rows
+    deg[rng.integers(0, n, size=200)] = 0                                  # empty rows
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(dtype)
+    items, crow, ce0, lrow, lc0 = _plan(rp)
+    L = 256
+    covered = np.zeros(n, np.int32)
+    for ra, rb in items:
+        assert 0 < rb - ra <= 64
+        covered[ra:rb] += 1
+        cost = (rp[rb] - rp[ra]) + (rb - ra)
+        assert cost <= 64 or rb - ra == 1 or cost - (deg[rb - 1] + 1) < 64
+        assert (deg[ra:rb] <= L).all()
+    covered[lrow] += 1
+    assert (covered == 1).all()
+    np.testing.assert_array_equal(np.sort(lrow), np.nonzero(deg > L)[0])
+    for j, r in enumerate(lrow):
+        c0, c1 = lc0[j], lc0[j + 1]
+        assert c1 - c0 == -(-deg[r] // L)
+        assert (crow[c0:c1] == r).all()
+        np.testing.assert_array_equal(ce0[c0:c1], rp[r] + L * np.arange(c1 - c0))
+
+
+def test_planner_rejects_bad_input():
+    L = _native.lib()
+    rp = np.array([0, 5, 3], np.int32)   # not monotone
+    ni = ctypes.c_int64()
+    rc = L.gcn_plan_count_host(rp.ctypes.data, 0, 2, 0, 0, ctypes.byref(ni), None, None)
+    assert rc == -1 and b"monotone" in L.gcn_last_error()
+    with pytest.raises(RuntimeError, match="monotone"):
+        _native.check(rc, "gcn_plan_count_host")
+
+
+def test_spmm_argument_errors_without_gpu():
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    L = _native.lib()
+    assert L.gcn_spmm_csr(None, 0, None, 0, None, 0, 4, None, 0, None, 0, None) == -1
+    p = _native.GcnCsrPlan()
+    p.n_rows, p.n_cols, p.nnz = 4, 4, 0
+    assert L.gcn_spmm_csr(ctypes.byref(p), 7, None, 4, None, 4, 4, None, 0, None, 0, None) == -1
+    assert b"dtype" in L.gcn_last_error()
+    assert L.gcn_spmm_workspace_bytes(ctypes.byref(p), 256) == 0
+    p.n_chunks = 3
+    assert L.gcn_spmm_workspace_bytes(ctypes.byref(p), 256) == 3 * 256 * 4
+
+
+def test_transpose_host_matches_oracle(oracle):
+    rows, cols, vals = gin.random_coo(60, 90, 700, seed=11, duplicates=50, empty_rows=(3, 4))
+    a = oracle.CSR.from_coo(rows, cols, vals, (60, 90))
+    L = _native.lib()
+    rp32 = a.rowptr.astype(np.int32)
+    rpt, ct, vt = np.zeros(91, np.int32), np.zeros(a.nnz, np.int32), np.zeros(a.nnz, np.float32)
+    rc = L.gcn_csr_transpose_host(rp32.ctypes.data, 0, a.col.ctypes.data, a.val.ctypes.data,
+                                  60, 90, rpt.ctypes.data, ct.ctypes.data, vt.ctypes.data)
+    assert rc == 0
+    o_rp, o_c, o_v = oracle.csr_transpose(a.rowptr, a.col, a.val, 90)
+    np.testing.assert_array_equal(rpt, o_rp)
+    np.testing.assert_array_equal(ct, o_c)
+    np.testing.assert_array_equal(vt, o_v)
+
+
+def test_module_surface_matches_reference():
+    from pygcn_amd import GCN, GraphConvolution
+    g1 = load_golden("g1_init.npz")
+    torch.manual_seed(42)
+    gc1, gc2 = GraphConvolution(1433, 16), GraphConvolution(16, 7)
+    # same RNG stream as the reference's init (layers.py:23-29): bit-identical parameters
+    np.testing.assert_array_equal(gc1.weight.detach().numpy(), g1["gc1_weight"])
+    np.testing.assert_array_equal(gc1.bias.detach().numpy(), g1["gc1_bias"])
+    np.testing.assert_array_equal(gc2.weight.detach().numpy(), g1["gc2_weight"])
+    np.testing.assert_array_equal(gc2.bias.detach().numpy(), g1["gc2_bias"])
+    assert repr(gc1) == str(g1["repr"])
+    assert (gc1.in_features, gc1.out_features) == (1433, 16)
+    nb = GraphConvolution(256, 256, bias=False)
+    assert nb.bias is None and list(nb.state_dict()) == ["weight"]
+    torch.manual_seed(7)
+    nb = GraphConvolution(256, 256, bias=False)
+    np.testing.assert_array_equal(nb.weight.detach().numpy()[:4], g1["nobias_weight_head"])
+    m = GCN(nfeat=1433, nhid=16, nclass=7, dropout=0.5)
+    assert list(m.state_dict()) == ["gc1.weight", "gc1.bias", "gc2.weight", "gc2.bias"]
+
+
+def test_flat_imports_like_the_reference():
+    """`from layers import GraphConvolution`, `from models import GCN`,
+    `from utils import load_data, accuracy` with cwd = the package dir (models.py:4,
+    train.py:15-16)."""
+    import subprocess
+    import sys
+    code = ("from layers import GraphConvolution; from models import GCN; "
+            "from utils import load_data, accuracy, normalize, sparse_mx_to_torch_sparse_tensor; "
+            "m = GCN(8, 4, 3, 0.5); print(type(m.gc1).__module__, m.gc1)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.join(ROOT, "pygcn_amd"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "GraphConvolution (8 -> 4)" in out.stdout and out.stdout.startswith("layers ")
+
+
+def test_load_data_reproduces_reference_adjacency():
+    from pygcn_amd.utils import load_data
+    g = load_golden("cora_graph.npz")
+    adj, feats, labels, itr, iva, ite = load_data()
+    assert adj.layout == torch.sparse_coo and adj.shape == (2708, 2708)
+    assert adj._indices().dtype == torch.int64 and adj._values().dtype == torch.float32
+    np.testing.assert_array_equal(adj._indices()[0].numpy(), g["coo_row"])
+    np.testing.assert_array_equal(adj._indices()[1].numpy(), g["coo_col"])
+    np.testing.assert_allclose(adj._values().numpy(), g["coo_val"], rtol=1e-7)
+    assert feats.shape == (2708, 1433) and labels.shape == (2708,)
+    np.testing.assert_allclose(feats.numpy(), gin.cora_features(), rtol=3e-7)
+    np.testing.assert_array_equal(labels.numpy(), gin.cora_labels())
+    assert (len(itr), len(iva), len(ite)) == (140, 300, 1000)
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the layer and the op raise on non-HIP tensors."""
+    from pygcn_amd import GraphConvolution, spmm
+    layer = GraphConvolution(4, 3)
+    adj = torch.eye(5).to_sparse()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        layer(torch.randn(5, 4), adj)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        spmm(adj, torch.randn(5, 3))
+
+
+def test_rmat_generator_shapes():
+    from pygcn_amd.utils import rmat_graph
+    n = 5000
+    rowptr, col, val = rmat_graph(n, 40000, seed=42, device="cpu")
+    assert rowptr.numel() == n + 1 and rowptr[0] == 0 and rowptr[-1] == col.numel()
+    deg = (rowptr[1:] - rowptr[:-1])
+    assert int(deg.min()) >= 1                      # self-loops
+    rows = torch.repeat_interleave(torch.arange(n), deg.long())
+    assert bool(((rows == col).sum() == n))         # exactly one diagonal entry per row
+    sums = torch.zeros(n).index_add_(0, rows, val)
+    np.testing.assert_allclose(sums.numpy(), 1.0, atol=1e-5)
+    key = rows * n + col
+    assert bool((key[1:] > key[:-1]).all())         # sorted, no duplicates
+    assert int(deg.max()) > 20 * float(deg.float().median())   # skewed
