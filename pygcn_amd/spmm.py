@@ -15,8 +15,18 @@ from .graph import CSRGraph, _require_cuda, as_graph
 
 _DTYPES = {torch.float32: _native.GCN_DTYPE_F32, torch.bfloat16: _native.GCN_DTYPE_BF16}
 
+# Optional launch timing for bench.py: when a list is installed here, every gcn_spmm_csr launch
+# is bracketed by HIP events recorded on the launch stream and (tag, start, end, graph) appended.
+_timing_records = None
 
-def spmm_csr(graph, B, bias=None, relu=False, out=None):
+
+def set_timing_records(records):
+    """Install (or remove, with None) the list that receives per-launch HIP event pairs."""
+    global _timing_records
+    _timing_records = records
+
+
+def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd"):
     """C = A · B (+ bias, ReLU) on the current HIP stream; A is a CSRGraph, B dense [n_cols, F]."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
@@ -47,10 +57,17 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=B.device) if ws_bytes else None
     with torch.cuda.device(B.device):
         stream = torch.cuda.current_stream().cuda_stream
+        rec = _timing_records
+        if rec is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         rc = L.gcn_spmm_csr(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                             out.data_ptr(), out.stride(0), F,
                             bias.data_ptr() if bias is not None else None, int(bool(relu)),
                             ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+        if rec is not None:
+            ev1.record()
+            rec.append((tag, ev0, ev1, graph))
     _native.check(rc, "gcn_spmm_csr")
     return out
 
@@ -70,7 +87,7 @@ class SpMMFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         grad_B = grad_bias = None
         if ctx.needs_input_grad[1]:
-            grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous())
+            grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.sum(0)
         return None, grad_B, grad_bias

@@ -185,8 +185,9 @@ def test_spmm_int64_rowptr_and_strided_operands(oracle, dev):
         assert not view.is_contiguous()
         out = spmm_csr(g, view)                       # ldb = 320 != F, offsets break alignment
         assert_normwise(out.cpu(), a.matmul(view.cpu().numpy()), TOL, f"strided F={F}")
-    assert_normwise(spmm_csr(g, big.t()[:900, :].contiguous()[:, :7]).cpu(),
-                    a.matmul(big.t()[:900, :7].cpu().numpy()), TOL, "non-unit stride input")
+    cm = torch.from_numpy(gin.dense((7, 900), 78)).to(dev).t()     # column-major [900, 7]
+    assert cm.stride(1) != 1
+    assert_normwise(spmm_csr(g, cm).cpu(), a.matmul(cm.cpu().numpy()), TOL, "non-unit stride")
 
 
 def test_fused_bias_relu_epilogue(oracle, dev):
