@@ -21,6 +21,7 @@ if not __package__:   # imported flat, the reference's convention (`from layers 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
 from pygcn_amd.spmm import SpMMFunction  # noqa: E402
+from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
 class GraphConvolution(Module):
@@ -50,6 +51,9 @@ class GraphConvolution(Module):
         + bias fused into the SpMM's store.  `adj`: CSRGraph, torch sparse COO/CSR (converted
         once and cached on the tensor) or a dense [N,N] tensor (the fork's live scripts pass a
         dense adjacency, utils.py:124-131 — torch.spmm is a dense GEMM there, and so is this)."""
+        if isinstance(adj, ShardedGraph):
+            # row-block shard of a multi-GPU run: all-gather + local HIP SpMM (pygcn_amd/sharded.py)
+            return ShardedSpMMFunction.apply(adj, torch.mm(input, self.weight), self.bias)
         _require_cuda(input, "input")
         _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
         support = torch.mm(input, self.weight)

@@ -1,0 +1,198 @@
+"""Row-block sharding of the GraphConvolution path over the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+The reference has no multi-device code at all; this is the scaling design for the
+same layer (reference pygcn/layers.py:32-38):
+
+  * Â is cut into P contiguous row blocks with (almost) equal numbers of stored entries; rank r
+    owns rows [b_r, b_r+1) of Â, of Âᵀ, of X, of every activation and gradient.  Weights are
+    replicated.
+  * forward   support_r = X_r · W  ->  ALL-GATHER support  ->  out_r = Â[b_r:b_r+1, :] · support
+  * backward  ALL-GATHER grad_out  ->  grad_support_r = Âᵀ[b_r:b_r+1, :] · grad_out, then the
+    local GEMMs, then ALL-REDUCE of grad_W / grad_b (256 KiB at F=256).
+  * The all-gather lands in a padded layout [P * max_rows, F] (every rank contributes max_rows
+    rows, the tail unused) and the column indices of the local blocks are remapped ONCE to that
+    layout, so the gathered buffer is consumed in place: no compaction copy, no all-gather-v.
+  * No float atomics, no reduce-scatter of N×F partial sums: each output row is produced by
+    exactly one rank.
+
+The local product is `pygcn_amd.spmm.spmm_csr` (HIP).  `graph_factory` / `spmm_fn` exist so the
+partition / exchange logic can be exercised on CPU with gloo in tests/, where tests/ (never this
+package) supplies the CPU oracle as the local product.
+"""
+import torch
+import torch.distributed as dist
+
+from .graph import CSRGraph
+from .spmm import spmm_csr
+
+
+def partition_rows(rowptr, world):
+    """Contiguous row-block boundaries (P+1 ints) balancing stored entries per block."""
+    n = rowptr.numel() - 1
+    nnz = int(rowptr[-1])
+    targets = torch.tensor([nnz * r // world for r in range(1, world)], dtype=rowptr.dtype,
+                           device=rowptr.device)
+    cuts = torch.searchsorted(rowptr, targets, right=False).clamp_(0, n).tolist()
+    bounds = [0] + cuts + [n]
+    for i in range(1, len(bounds)):          # monotone even for degenerate inputs
+        bounds[i] = max(bounds[i], bounds[i - 1])
+    return bounds
+
+
+def remap_columns(col, bounds, max_rows):
+    """Global column id -> row of the padded gathered buffer [P*max_rows, F]."""
+    b = torch.tensor(bounds, dtype=torch.int64, device=col.device)
+    owner = torch.searchsorted(b, col.to(torch.int64), right=True) - 1
+    owner.clamp_(0, len(bounds) - 2)
+    return (col.to(torch.int64) - b[owner] + owner * max_rows).to(torch.int32)
+
+
+def row_block(rowptr, col, val, r0, r1):
+    """Rows [r0, r1) of a CSR matrix as (rebased rowptr, col, val)."""
+    e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+    return (rowptr[r0:r1 + 1] - rowptr[r0]), col[e0:e1], val[e0:e1]
+
+
+def transpose_row_block(rowptr, col, val, n_rows, r0, r1):
+    """Rows [r0, r1) of Aᵀ (= columns [r0, r1) of A) as CSR with global source-row ids as columns;
+    entries of a row in increasing source-row order (deterministic sums)."""
+    dev = col.device
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    src = torch.repeat_interleave(torch.arange(n_rows, device=dev, dtype=torch.int32), deg)
+    keep = (col >= r0) & (col < r1)
+    c, s, v = col[keep].to(torch.int64) - r0, src[keep], val[keep]
+    del src, keep
+    _, perm = torch.sort(c, stable=True)
+    counts = torch.bincount(c, minlength=r1 - r0) if c.numel() else torch.zeros(
+        r1 - r0, dtype=torch.int64, device=dev)
+    rp = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rp[1:])
+    return rp.to(rowptr.dtype), s[perm], v[perm]
+
+
+class ShardedGraph:
+    """Rank-local view of Â: the row block of Â and of Âᵀ, both with columns remapped to the
+    padded all-gather layout.  Accepted as `adj` by GraphConvolution.forward."""
+
+    def __init__(self, bounds, rank, world, a_block, at_block, group=None,
+                 graph_factory=CSRGraph, spmm_fn=spmm_csr, **plan_kw):
+        self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
+        self.n_global = bounds[-1]
+        self.r0, self.r1 = bounds[rank], bounds[rank + 1]
+        self.n_local = self.r1 - self.r0
+        self.max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
+        n_pad = self.world * self.max_rows
+        self._spmm = spmm_fn
+        rp, c, v = a_block
+        self.nnz_local = int(c.numel())
+        self.A = graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
+                               (self.n_local, n_pad), **plan_kw)
+        rp, c, v = at_block
+        self.At = graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
+                                (self.n_local, n_pad), **plan_kw)
+        self.timing = None    # optional list: (tag, start_event, end_event) per exchange+product
+
+    @classmethod
+    def from_global_csr(cls, rowptr, col, val, n, rank, world, device=None, group=None, **kw):
+        """Every rank holds (or has generated) the same global CSR; keep this rank's blocks."""
+        bounds = partition_rows(rowptr, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        a_block = row_block(rowptr, col, val, r0, r1)
+        at_block = transpose_row_block(rowptr, col, val, n, r0, r1)
+        if device is not None:
+            a_block = tuple(t.to(device) for t in a_block)
+            at_block = tuple(t.to(device) for t in at_block)
+        return cls(bounds, rank, world, a_block, at_block, group=group, **kw)
+
+    # ---------------------------------------------------------------- exchange step
+    def all_gather_rows(self, local):
+        """[n_local, F] on every rank -> padded [P*max_rows, F] (rows past n_local of each slot
+        are never referenced by the remapped column indices)."""
+        F = local.shape[1]
+        out = torch.empty((self.world * self.max_rows, F), dtype=local.dtype, device=local.device)
+        slot = out[self.rank * self.max_rows:(self.rank + 1) * self.max_rows]
+        slot[:self.n_local].copy_(local)
+        if self.n_local < self.max_rows:
+            slot[self.n_local:].zero_()
+        dist.all_gather_into_tensor(out, slot, group=self.group)   # in-place form
+        return out
+
+    def product(self, local, transpose=False, bias=None):
+        ev = None
+        if self.timing is not None and local.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        gathered = self.all_gather_rows(local)
+        out = self._spmm(self.At if transpose else self.A, gathered, bias=bias,
+                         tag="bwd_local" if transpose else "fwd_local")
+        if ev is not None:
+            ev[1].record()
+            self.timing.append(("bwd" if transpose else "fwd", ev[0], ev[1]))
+        return out
+
+    def __repr__(self):
+        return (f"ShardedGraph(rank {self.rank}/{self.world}, rows [{self.r0},{self.r1}) of "
+                f"{self.n_global}, nnz_local {self.nnz_local})")
+
+
+class ShardedSpMMFunction(torch.autograd.Function):
+    """out_r = Â_r · allgather(support);  grad_support_r = (Âᵀ)_r · allgather(grad_out)."""
+
+    @staticmethod
+    def forward(ctx, sg, support_local, bias):
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        return sg.product(support_local, transpose=False, bias=bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_support = grad_bias = None
+        if ctx.needs_input_grad[1]:
+            grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_out.sum(0)          # partial: summed over ranks by allreduce_grads
+        return None, grad_support, grad_bias
+
+
+class ShardedGCN(torch.nn.Module):
+    """A replicated GCN driven on row-block shards: forward(x_local, sharded_adj)."""
+
+    def __init__(self, model, sg):
+        super().__init__()
+        self.model, self.sg = model, sg
+        self._flat = None
+
+    def forward(self, x_local, sg=None):
+        return self.model(x_local, sg if sg is not None else self.sg)
+
+    def nll_loss(self, logp_local, labels_local, idx_local=None):
+        """This rank's share of the global-mean NLL over the (optionally index-selected) nodes of
+        all ranks: local sum / global count.  Backpropagating it on every rank and summing the
+        parameter gradients (allreduce_grads) gives the gradient of the global mean."""
+        if idx_local is not None:
+            logp_local, labels_local = logp_local[idx_local], labels_local[idx_local]
+        cnt = torch.tensor([float(labels_local.numel())], device=logp_local.device)
+        dist.all_reduce(cnt, group=self.sg.group)
+        s = torch.nn.functional.nll_loss(logp_local, labels_local, reduction="sum") \
+            if labels_local.numel() else logp_local.sum() * 0.0
+        return s / cnt[0]
+
+    def global_loss(self, loss_share):
+        """Sum of the ranks' shares = the global-mean loss (for reporting)."""
+        t = loss_share.detach().clone().reshape(1)
+        dist.all_reduce(t, group=self.sg.group)
+        return float(t.item())
+
+    def allreduce_grads(self):
+        """Sum parameter gradients over ranks (one flat bucket; 2·F² + 2·F floats)."""
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        if not params:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, group=self.sg.group)
+        off = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n

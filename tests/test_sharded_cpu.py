@@ -1,0 +1,141 @@
+"""Multi-process tests of the row-block sharded path on CPU (gloo, world_size 2 and 3).
+
+The partition, column remap, padded all-gather, autograd exchange and gradient all-reduce are the
+product's code (pygcn_amd/sharded.py); only the rank-local product is supplied by the test as the
+CPU oracle (tests may use the oracle; the product never does).  The sharded result must equal
+the unsharded oracle result on the whole graph."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _CpuGraph:
+    """Oracle-backed stand-in for CSRGraph (CPU tensors)."""
+
+    def __init__(self, rowptr, col, val, shape, **_):
+        self.rowptr, self.col, self.val, self.shape = rowptr, col, val, tuple(shape)
+        self.nnz = int(col.numel())
+
+
+def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd"):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gcn_oracle
+    assert B.shape[0] == graph.shape[1]
+    y = gcn_oracle.spmm_csr(graph.rowptr.numpy(), graph.col.numpy(), graph.val.numpy(),
+                            B.detach().numpy())
+    if bias is not None:
+        y = y + bias.detach().numpy()
+    return torch.from_numpy(y)
+
+
+def _worker(rank, world, port, n, n_edges, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import gcn_oracle
+    from pygcn_amd import GCN
+    from pygcn_amd.sharded import ShardedGCN, ShardedGraph
+    from pygcn_amd.utils import rmat_graph
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fin, nhid, ncls = 24, 32, 16
+        rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")   # same on every rank
+        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world,
+                                          graph_factory=_CpuGraph, spmm_fn=_cpu_spmm)
+        assert sg.bounds[0] == 0 and sg.bounds[-1] == n and sg.n_local == sg.r1 - sg.r0
+        x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, fin)).astype(np.float32))
+        labels = torch.from_numpy(np.random.default_rng(2).integers(0, ncls, n))
+        train = torch.from_numpy(np.sort(np.random.default_rng(3).choice(n, n // 5, False)))
+        torch.manual_seed(42)
+        model = GCN(fin, nhid, ncls, dropout=0.0)
+        smodel = ShardedGCN(model, sg)
+        model.train()
+        x_loc, y_loc = x[sg.r0:sg.r1], labels[sg.r0:sg.r1]
+        idx_loc = train[(train >= sg.r0) & (train < sg.r1)] - sg.r0
+        logp = smodel(x_loc, sg)
+        loss = smodel.nll_loss(logp, y_loc, idx_loc)
+        loss.backward()
+        smodel.allreduce_grads()
+
+        # unsharded oracle on the whole graph
+        a = gcn_oracle.CSR(rowptr.numpy(), col.numpy(), val.numpy(), (n, n))
+        p = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+        ref_loss, fw, grads, _ = gcn_oracle.gcn2_loss_backward(x.numpy(), a, p, labels.numpy(),
+                                                                train.numpy())
+
+        def close(got, ref, what, rel=1e-5):
+            err = np.abs(np.asarray(got, np.float64) - ref).max()
+            assert err <= rel * np.abs(ref).max(), f"rank {rank}: {what} off by {err:.3e}"
+        close(logp.detach().numpy(), fw["logp"][sg.r0:sg.r1], "logp block")
+        gl = smodel.global_loss(loss)
+        assert abs(gl - ref_loss) <= 1e-5 * abs(ref_loss), (gl, ref_loss)
+        for k, v in grads.items():
+            mod, name = k.split(".")
+            close(getattr(getattr(model, mod), name).grad.numpy(), v, k + ".grad", rel=2e-5)
+        # blocks are nnz-balanced and cover every stored entry exactly once
+        tot = torch.tensor([float(sg.nnz_local), float(sg.At.nnz)])
+        dist.all_reduce(tot)
+        assert int(tot[0]) == int(tot[1]) == int(col.numel())
+        assert abs(sg.nnz_local - col.numel() / world) <= 0.15 * col.numel() / world + int(
+            (rowptr[1:] - rowptr[:-1]).max())
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gcn_matches_unsharded_oracle(world, tmp_path, oracle):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, 4000, 30000, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_partition_and_remap_are_consistent():
+    sys.path.insert(0, ROOT)
+    from pygcn_amd.sharded import partition_rows, remap_columns, row_block, transpose_row_block
+    from pygcn_amd.utils import rmat_graph
+    n = 2500
+    rowptr, col, val = rmat_graph(n, 20000, seed=9, device="cpu")
+    for world in (1, 2, 4, 8):
+        b = partition_rows(rowptr, world)
+        assert len(b) == world + 1 and b[0] == 0 and b[-1] == n and sorted(b) == b
+        max_rows = max(b[i + 1] - b[i] for i in range(world))
+        rc = remap_columns(col, b, max_rows).long()
+        owner = rc // max_rows
+        back = rc - owner * max_rows + torch.tensor(b)[owner]
+        assert torch.equal(back, col.long())                  # remap is invertible
+        assert bool(((rc % max_rows) < (torch.tensor(b)[owner + 1] - torch.tensor(b)[owner])).all())
+        cover = 0
+        for r in range(world):
+            rp, c, v = row_block(rowptr, col, val, b[r], b[r + 1])
+            assert rp[0] == 0 and rp[-1] == c.numel() == v.numel()
+            cover += c.numel()
+            rpt, ct, vt = transpose_row_block(rowptr, col, val, n, b[r], b[r + 1])
+            assert rpt.numel() == b[r + 1] - b[r] + 1 and rpt[-1] == ct.numel()
+            # dense check of the transposed block
+            dense = torch.zeros(n, n)
+            rows = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).long())
+            dense[rows, col.long()] = val
+            blk = torch.zeros(b[r + 1] - b[r], n)
+            trow = torch.repeat_interleave(torch.arange(b[r + 1] - b[r]),
+                                           (rpt[1:] - rpt[:-1]).long())
+            blk[trow, ct.long()] = vt
+            assert torch.equal(blk, dense.t()[b[r]:b[r + 1]])
+        assert cover == col.numel()
