@@ -20,7 +20,7 @@ from torch.nn.parameter import Parameter
 if not __package__:   # imported flat, the reference's convention (`from layers import ...`)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
-from pygcn_amd.spmm import SpMMFunction  # noqa: E402
+from pygcn_amd.spmm import DenseMMFunction, SpMMFunction  # noqa: E402
 from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
@@ -46,21 +46,27 @@ class GraphConvolution(Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj):
+    def forward(self, input, adj, relu=False):
         """support = input @ W (MFMA GEMM via torch.mm), output = adj @ support (HIP SpMM),
         + bias fused into the SpMM's store.  `adj`: CSRGraph, torch sparse COO/CSR (converted
-        once and cached on the tensor) or a dense [N,N] tensor (the fork's live scripts pass a
-        dense adjacency, utils.py:124-131 — torch.spmm is a dense GEMM there, and so is this)."""
+        once and cached on the tensor), a ShardedGraph (multi-GPU row block), or a dense [N,N]
+        tensor (the fork's live scripts pass a dense adjacency, utils.py:124-131 — torch.spmm is
+        a dense GEMM there, and so is this).
+
+        `relu=True` (an extension; default is the reference's behaviour) applies the ReLU that
+        follows the layer in the model (models.py:48 upstream) inside the kernel's store."""
         if isinstance(adj, ShardedGraph):
             # row-block shard of a multi-GPU run: all-gather + local HIP SpMM (pygcn_amd/sharded.py)
-            return ShardedSpMMFunction.apply(adj, torch.mm(input, self.weight), self.bias)
+            return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
+                                             self.bias, relu)
         _require_cuda(input, "input")
         _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
-        support = torch.mm(input, self.weight)
         if isinstance(adj, torch.Tensor) and adj.layout == torch.strided:
-            output = torch.mm(adj, support)
-            return output + self.bias if self.bias is not None else output
-        return SpMMFunction.apply(as_graph(adj), support, self.bias)
+            output = torch.mm(adj, torch.mm(input, self.weight))
+            output = output + self.bias if self.bias is not None else output
+            return torch.relu(output) if relu else output
+        support = DenseMMFunction.apply(input, self.weight)
+        return SpMMFunction.apply(as_graph(adj), support, self.bias, relu)
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' \

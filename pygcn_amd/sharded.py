@@ -118,13 +118,13 @@ class ShardedGraph:
         dist.all_gather_into_tensor(out, slot, group=self.group)   # in-place form
         return out
 
-    def product(self, local, transpose=False, bias=None):
+    def product(self, local, transpose=False, bias=None, relu=False):
         ev = None
         if self.timing is not None and local.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         gathered = self.all_gather_rows(local)
-        out = self._spmm(self.At if transpose else self.A, gathered, bias=bias,
+        out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
                          tag="bwd_local" if transpose else "fwd_local")
         if ev is not None:
             ev[1].record()
@@ -140,19 +140,26 @@ class ShardedSpMMFunction(torch.autograd.Function):
     """out_r = Â_r · allgather(support);  grad_support_r = (Âᵀ)_r · allgather(grad_out)."""
 
     @staticmethod
-    def forward(ctx, sg, support_local, bias):
+    def forward(ctx, sg, support_local, bias, relu=False):
         ctx.sg = sg
         ctx.has_bias = bias is not None
-        return sg.product(support_local, transpose=False, bias=bias)
+        ctx.relu = bool(relu)
+        out = sg.product(support_local, transpose=False, bias=bias, relu=relu)
+        if relu:
+            ctx.save_for_backward(out)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         grad_support = grad_bias = None
+        if ctx.relu:
+            (out,) = ctx.saved_tensors
+            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0)
         if ctx.needs_input_grad[1]:
             grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.sum(0)          # partial: summed over ranks by allreduce_grads
-        return None, grad_support, grad_bias
+        return None, grad_support, grad_bias, None
 
 
 class ShardedGCN(torch.nn.Module):

@@ -73,24 +73,68 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd"):
 
 
 class SpMMFunction(torch.autograd.Function):
-    """out = A · B [+ bias];  grad_B = A^T · grad_out;  grad_bias = column sums of grad_out.
+    """out = [relu](A · B [+ bias]);  grad_B = A^T · grad_pre;  grad_bias = column sums of
+    grad_pre, where grad_pre = grad_out (masked by out > 0 when the ReLU was fused).
     `adj` never receives a gradient (it is a loaded constant in the reference: train.py:80,123).
-    Only the graph handle is kept for backward — not B."""
+    Only the graph handle (and the output, for a fused ReLU) is kept for backward — not B."""
 
     @staticmethod
-    def forward(ctx, graph, B, bias):
+    def forward(ctx, graph, B, bias, relu=False):
         ctx.graph = graph
         ctx.has_bias = bias is not None
-        return spmm_csr(graph, B, bias=bias)
+        ctx.relu = bool(relu)
+        out = spmm_csr(graph, B, bias=bias, relu=relu)
+        if relu:
+            ctx.save_for_backward(out)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         grad_B = grad_bias = None
+        if ctx.relu:
+            (out,) = ctx.saved_tensors
+            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0)
         if ctx.needs_input_grad[1]:
             grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.sum(0)
-        return None, grad_B, grad_bias
+        return None, grad_B, grad_bias, None
+
+
+class DenseMMFunction(torch.autograd.Function):
+    """`torch.mm(input, weight)` (reference pygcn/layers.py:33) with a K-split weight gradient.
+
+    grad_W = inputᵀ · grad is a [Fin, N]·[N, Fout] GEMM whose reduction runs over the N graph
+    vertices (10⁷ at config C4).  hipBLASLt answers that shape with a stream-K kernel at 21.5 ms;
+    cutting N into 128 slabs, one batched GEMM over the slabs and a sum of the 128 small partial
+    products takes 8.7 ms on MI355X (tools/gemm_probe.py) and is at least as accurate (shorter
+    fp32 accumulation chains)."""
+
+    K_SPLIT = 128
+    MIN_ROWS = 1 << 17
+
+    @staticmethod
+    def forward(ctx, input, weight):
+        ctx.save_for_backward(input, weight)
+        return torch.mm(input, weight)
+
+    @staticmethod
+    def backward(ctx, grad):
+        input, weight = ctx.saved_tensors
+        grad_in = grad_w = None
+        if ctx.needs_input_grad[0]:
+            grad_in = torch.mm(grad, weight.t())
+        if ctx.needs_input_grad[1]:
+            n, b = input.shape[0], DenseMMFunction.K_SPLIT
+            if n >= DenseMMFunction.MIN_ROWS and input.is_contiguous() and grad.is_contiguous():
+                m = n // b * b
+                grad_w = torch.bmm(input[:m].view(b, m // b, -1).transpose(1, 2),
+                                   grad[:m].view(b, m // b, -1)).sum(0)
+                if m < n:
+                    grad_w = grad_w + torch.mm(input[m:].t(), grad[m:])
+            else:
+                grad_w = torch.mm(input.t(), grad)
+        return grad_in, grad_w
 
 
 def spmm(adj, dense, bias=None):

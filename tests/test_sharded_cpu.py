@@ -39,6 +39,8 @@ def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd"):
                             B.detach().numpy())
     if bias is not None:
         y = y + bias.detach().numpy()
+    if relu:
+        y = np.maximum(y, 0)
     return torch.from_numpy(y)
 
 
