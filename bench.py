@@ -57,6 +57,8 @@ def parse():
                     help="time only forward SpMM launches (profiling aid; not the graded mode)")
     ap.add_argument("--item-cost", type=int, default=0)
     ap.add_argument("--long-thresh", type=int, default=0)
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="multi-GPU exchange step: rows a rank references only, or full all-gather")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -187,7 +189,8 @@ def main():
         fwd_model = model
     else:
         from pygcn_amd.sharded import ShardedGraph, ShardedGCN
-        adj = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, dev, **kw)
+        adj = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, dev,
+                                           exchange=args.exchange, **kw)
         del rowptr, col, val
         n_local, nnz_local = adj.n_local, adj.nnz_local
         gen.manual_seed(44 + rank)
@@ -283,7 +286,10 @@ def main():
                                    f"{feat}->{feat}->{feat}, fwd+bwd+Adam, dropout {args.dropout}, NLL on the "
                                    f"first 140/2708 of the vertices (upstream idx_train share)",
                        "nodes": n_total, "nnz": nnz_total, "feat_dim": feat,
-                       "parallelism": f"row-block x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"row-block x{world}, {args.exchange} exchange, rank0 "
+                                       f"receives {adj.exchange_rows()[0]} of "
+                                       f"{adj.exchange_rows()[1]} remote rows per product")
+                       if world > 1 else "single GPU",
                        "mode": "spmm-only" if args.spmm_only else "train-epoch"},
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,

@@ -15,6 +15,14 @@ same layer (reference pygcn/layers.py:32-38):
     layout, so the gathered buffer is consumed in place: no compaction copy, no all-gather-v.
   * No float atomics, no reduce-scatter of N×F partial sums: each output row is produced by
     exactly one rank.
+  * Exchange modes.  "allgather" moves every row to every rank (P-1)/P·N·F·s bytes in per rank.
+    "halo" (default) moves a row only to the ranks whose block references it: at setup every rank
+    sends each owner the sorted list of that owner's rows it needs (one grouped P2P round); per
+    product the owner packs those rows (index_select) and one grouped isend/irecv round lands them
+    behind the rank's own rows in a compact buffer [n_local + n_halo, F], to which the local
+    column ids were remapped once.  On R-MAT graphs more than half of the rows are referenced by
+    no remote rank at all (self-loop-only vertices), and xGMI is point-to-point, so sending only
+    what is needed, directly owner -> consumer, is the right shape for it.
 
 The local product is `pygcn_amd.spmm.spmm_csr` (HIP).  `graph_factory` / `spmm_fn` exist so the
 partition / exchange logic can be exercised on CPU with gloo in tests/, where tests/ (never this
@@ -71,26 +79,112 @@ def transpose_row_block(rowptr, col, val, n_rows, r0, r1):
     return rp.to(rowptr.dtype), s[perm], v[perm]
 
 
+def _p2p_round(sends, recvs, group):
+    """One grouped round of point-to-point transfers: sends = [(tensor, peer)], recvs likewise.
+    Zero-length transfers are skipped on both sides (counts are known everywhere)."""
+    ops = [dist.P2POp(dist.isend, t, peer, group) for t, peer in sends if t.numel()] + \
+          [dist.P2POp(dist.irecv, t, peer, group) for t, peer in recvs if t.numel()]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+class HaloExchange:
+    """Which rows of every other rank's block this rank's CSR block references, and the send
+    lists the other ranks asked of this rank.  Built once per (block, process group)."""
+
+    def __init__(self, col_global, bounds, rank, world, group=None):
+        dev = col_global.device
+        self.rank, self.world, self.group = rank, world, group
+        b = torch.tensor(bounds, dtype=torch.int64, device=dev)
+        self.n_local = bounds[rank + 1] - bounds[rank]
+        needed = torch.unique(col_global.to(torch.int64))            # sorted global row ids
+        pos = torch.searchsorted(needed, b)                           # split by owner
+        pos_l = pos.tolist()
+        need = [(needed[pos_l[r]:pos_l[r + 1]] - bounds[r]).to(torch.int32) for r in range(world)]
+        recv_counts = [int(need[r].numel()) if r != rank else 0 for r in range(world)]
+        # counts matrix M[s][r] = rows of r that s needs
+        mine = torch.tensor(recv_counts, dtype=torch.int64, device=dev)
+        M = torch.empty(world * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(M, mine, group=group)
+        M = M.view(world, world).tolist()
+        self.recv_counts = recv_counts
+        self.send_counts = [M[s][rank] if s != rank else 0 for s in range(world)]
+        # request lists: I tell every owner which of its rows I need
+        asked = [torch.empty(self.send_counts[s], dtype=torch.int32, device=dev)
+                 for s in range(world)]
+        _p2p_round([(need[r], r) for r in range(world) if r != rank],
+                   [(asked[s], s) for s in range(world) if s != rank], group)
+        self.send_idx = torch.cat([asked[s] for s in range(world) if s != rank]).to(torch.int64) \
+            if world > 1 else torch.empty(0, dtype=torch.int64, device=dev)
+        if self.send_idx.numel():
+            assert int(self.send_idx.max()) < self.n_local and int(self.send_idx.min()) >= 0
+        self.n_halo = sum(recv_counts)
+        self.n_send = sum(self.send_counts)
+        # compact layout: [own rows | halo rows of rank 0 | rank 1 | ...]; remap the column ids
+        halo_off, acc = [], 0
+        for r in range(world):
+            halo_off.append(acc)
+            acc += recv_counts[r]
+        self.halo_off = halo_off
+        c = col_global.to(torch.int64)
+        owner = (torch.searchsorted(b, c, right=True) - 1).clamp_(0, world - 1)
+        idx = torch.searchsorted(needed, c)
+        base = torch.tensor([self.n_local + halo_off[r] - pos_l[r] for r in range(world)],
+                            dtype=torch.int64, device=dev)
+        self.col_local = torch.where(owner == rank, c - bounds[rank], base[owner] + idx) \
+            .to(torch.int32)
+        self.n_buf = self.n_local + self.n_halo
+
+    def exchange(self, local):
+        """[n_local, F] -> [n_local + n_halo, F]: own rows followed by the referenced remote rows."""
+        F = local.shape[1]
+        buf = torch.empty((self.n_buf, F), dtype=local.dtype, device=local.device)
+        buf[:self.n_local].copy_(local)
+        if self.world == 1:
+            return buf
+        packed = local.index_select(0, self.send_idx)
+        sends, recvs, so = [], [], 0
+        for k in range(1, self.world):
+            s = (self.rank + k) % self.world
+            off = sum(self.send_counts[q] for q in range(s) if q != self.rank)
+            sends.append((packed[off:off + self.send_counts[s]], s))
+        for k in range(1, self.world):
+            r = (self.rank - k) % self.world
+            o = self.n_local + self.halo_off[r]
+            recvs.append((buf[o:o + self.recv_counts[r]], r))
+        _p2p_round(sends, recvs, self.group)
+        return buf
+
+
 class ShardedGraph:
     """Rank-local view of Â: the row block of Â and of Âᵀ, both with columns remapped to the
     padded all-gather layout.  Accepted as `adj` by GraphConvolution.forward."""
 
-    def __init__(self, bounds, rank, world, a_block, at_block, group=None,
+    def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
                  graph_factory=CSRGraph, spmm_fn=spmm_csr, **plan_kw):
+        if exchange not in ("halo", "allgather"):
+            raise RuntimeError("exchange must be 'halo' or 'allgather'")
         self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
+        self.exchange_mode = exchange
         self.n_global = bounds[-1]
         self.r0, self.r1 = bounds[rank], bounds[rank + 1]
         self.n_local = self.r1 - self.r0
         self.max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
-        n_pad = self.world * self.max_rows
         self._spmm = spmm_fn
-        rp, c, v = a_block
-        self.nnz_local = int(c.numel())
-        self.A = graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
-                               (self.n_local, n_pad), **plan_kw)
-        rp, c, v = at_block
-        self.At = graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
-                                (self.n_local, n_pad), **plan_kw)
+        self.nnz_local = int(a_block[1].numel())
+        self.halo = self.halo_t = None
+        blocks = []
+        for rp, c, v in (a_block, at_block):
+            if exchange == "halo":
+                h = HaloExchange(c, bounds, rank, world, group)
+                blocks.append((graph_factory(rp, h.col_local, v, (self.n_local, h.n_buf),
+                                             **plan_kw), h))
+            else:
+                n_pad = self.world * self.max_rows
+                blocks.append((graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
+                                             (self.n_local, n_pad), **plan_kw), None))
+        (self.A, self.halo), (self.At, self.halo_t) = blocks
         self.timing = None    # optional list: (tag, start_event, end_event) per exchange+product
 
     @classmethod
@@ -123,7 +217,10 @@ class ShardedGraph:
         if self.timing is not None and local.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        gathered = self.all_gather_rows(local)
+        if self.exchange_mode == "halo":
+            gathered = (self.halo_t if transpose else self.halo).exchange(local)
+        else:
+            gathered = self.all_gather_rows(local)
         out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
                          tag="bwd_local" if transpose else "fwd_local")
         if ev is not None:
@@ -131,9 +228,14 @@ class ShardedGraph:
             self.timing.append(("bwd" if transpose else "fwd", ev[0], ev[1]))
         return out
 
+    def exchange_rows(self):
+        """(rows received per forward product, rows an all-gather would have received)."""
+        recv = self.halo.n_halo if self.halo is not None else self.n_global - self.n_local
+        return recv, self.n_global - self.n_local
+
     def __repr__(self):
         return (f"ShardedGraph(rank {self.rank}/{self.world}, rows [{self.r0},{self.r1}) of "
-                f"{self.n_global}, nnz_local {self.nnz_local})")
+                f"{self.n_global}, nnz_local {self.nnz_local}, exchange {self.exchange_mode})")
 
 
 class ShardedSpMMFunction(torch.autograd.Function):

@@ -44,7 +44,7 @@ def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd"):
     return torch.from_numpy(y)
 
 
-def _worker(rank, world, port, n, n_edges, out_dir):
+def _worker(rank, world, port, n, n_edges, out_dir, exchange):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -58,8 +58,10 @@ def _worker(rank, world, port, n, n_edges, out_dir):
     try:
         fin, nhid, ncls = 24, 32, 16
         rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")   # same on every rank
-        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world,
+        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, exchange=exchange,
                                           graph_factory=_CpuGraph, spmm_fn=_cpu_spmm)
+        recv, full = sg.exchange_rows()
+        assert recv <= full and (exchange == "allgather") == (recv == full and sg.halo is None)
         assert sg.bounds[0] == 0 and sg.bounds[-1] == n and sg.n_local == sg.r1 - sg.r0
         x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, fin)).astype(np.float32))
         labels = torch.from_numpy(np.random.default_rng(2).integers(0, ncls, n))
@@ -101,11 +103,13 @@ def _worker(rank, world, port, n, n_edges, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gcn_matches_unsharded_oracle(world, tmp_path, oracle):
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "allgather"),
+                                            (3, "allgather")])
+def test_sharded_gcn_matches_unsharded_oracle(world, exchange, tmp_path, oracle):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, 4000, 30000, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, 4000, 30000, str(tmp_path), exchange), nprocs=world,
+             join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
@@ -141,3 +145,37 @@ def test_partition_and_remap_are_consistent():
             blk[trow, ct.long()] = vt
             assert torch.equal(blk, dense.t()[b[r]:b[r + 1]])
         assert cover == col.numel()
+
+
+def _halo_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygcn_amd.sharded import HaloExchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bounds = [0, 5, 5, 12, 20]           # rank 1 owns nothing
+        n = bounds[-1]
+        # block structure: rank 0 references only its own rows; rank 2 references rows of 0 and 3;
+        # rank 3 references row 19 (own) and row 0
+        cols = {0: [0, 1, 4, 4, 2], 1: [], 2: [0, 19, 7, 3, 12, 12, 19], 3: [19, 0]}[rank]
+        col = torch.tensor(cols, dtype=torch.int32)
+        h = HaloExchange(col, bounds, rank, world)
+        table = torch.arange(n, dtype=torch.float32).view(n, 1) * torch.tensor([[1.0, 10.0]])
+        local = table[bounds[rank]:bounds[rank + 1]].contiguous()
+        buf = h.exchange(local)
+        assert buf.shape == (h.n_buf, 2)
+        got = buf[h.col_local.long()]
+        assert torch.equal(got, table[col.long()]), (rank, got, table[col.long()])
+        expect_halo = {0: 0, 1: 0, 2: 4, 3: 1}[rank]      # distinct remote rows referenced
+        assert h.n_halo == expect_halo
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_degenerate_blocks(tmp_path):
+    """Empty block, ranks that need nothing, duplicate references, zero-length transfers."""
+    import torch.multiprocessing as mp
+    mp.spawn(_halo_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(4)]

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, n_edges, out_dir):
+def _worker(rank, world, port, n, n_edges, out_dir, exchange):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -43,11 +43,24 @@ def _worker(rank, world, port, n, n_edges, out_dir):
         real_ar(c, op=op, group=group)
         t.copy_(c)
     dist.all_gather_into_tensor, dist.all_reduce = ag, ar
+    import pygcn_amd.sharded as sh
+    real_p2p = sh._p2p_round
+
+    def p2p(sends, recvs, group):   # grouped isend/irecv staged through the host
+        hs = [(t.cpu(), peer) for t, peer in sends]
+        hr = [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
+        real_p2p(hs, hr, group)
+        for (t, _), (h, _) in zip(recvs, hr):
+            t.copy_(h)
+    sh._p2p_round = p2p
     try:
         dev = torch.device("cuda:0")
         F = 256
         rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")
-        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, device=dev)
+        sg = ShardedGraph.from_global_csr(rowptr.to(dev), col.to(dev), val.to(dev), n, rank, world,
+                                          exchange=exchange)
+        recv, full = sg.exchange_rows()
+        assert (recv < 0.8 * full) if exchange == "halo" else recv == full
         x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, F)).astype(np.float32))
         labels = torch.from_numpy(np.random.default_rng(2).integers(0, F, n))
         torch.manual_seed(42)
@@ -81,8 +94,10 @@ def _worker(rank, world, port, n, n_edges, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path):
+@pytest.mark.parametrize("exchange", ["halo", "allgather"])
+def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, exchange):
     assert torch.cuda.is_available()
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), 60000, 600000, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), 60000, 600000, str(tmp_path), exchange), nprocs=2,
+             join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
