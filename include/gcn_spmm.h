@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 1
+#define GCN_ABI_VERSION 2
 
 /*
  * A CSR adjacency (or its transpose) plus the static launch schedule built for it once.
@@ -119,6 +119,36 @@ size_t gcn_spmm_workspace_bytes(const gcn_csr_plan *plan, int64_t F);
 int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
                  int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
                  size_t workspace_bytes, void *stream);
+
+/*
+ * Epilogue applied to every output row inside the kernel's store, in this order:
+ *   x = acc + bias[f]            (bias may be NULL)          — pygcn/layers.py:35-36
+ *   x = max(x, 0)                if relu                     — F.relu,   pygcn/models.py:48 (upstream)
+ *   x = keep ? x / (1 - p) : 0   if dropout_p > 0            — F.dropout, pygcn/models.py:50 (upstream)
+ * The keep bit of element (row, f) is word (f & 3) of Philox4x32-10(counter = (row, f >> 2),
+ * key = seed) compared with p * 2^32: a pure function of (seed, row, f), identical for every
+ * kernel variant.  Because out > 0 <=> (pre-activation > 0 and kept), no mask is stored: the
+ * backward pass is gcn_relu_dropout_backward on the output itself.
+ */
+typedef struct gcn_epilogue {
+    const float *bias;   /* DEVICE fp32 [F] or NULL */
+    int32_t relu;
+    float dropout_p;     /* in [0, 1); 0 disables dropout */
+    uint64_t seed;
+} gcn_epilogue;
+
+/* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */
+int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
+                    int64_t ldc, int64_t F, const gcn_epilogue *ep, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
+/*
+ * grad_pre[i] = out[i] > 0 ? grad_out[i] * scale : 0 over n_elems contiguous elements
+ * (scale = 1 / (1 - p); 1 for a bare ReLU).  DEVICE pointers; grad_pre may alias grad_out.
+ * Backward of the fused epilogue above (autograd of F.relu + F.dropout in the reference model).
+ */
+int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, void *grad_pre,
+                              int64_t n_elems, float scale, void *stream);
 
 /*
  * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 1
+GCN_ABI_VERSION = 2
 GCN_DTYPE_F32 = 0
 GCN_DTYPE_BF16 = 1
 
@@ -32,9 +32,16 @@ class GcnCsrPlan(ctypes.Structure):
     ]
 
 
+class GcnEpilogue(ctypes.Structure):
+    """Mirror of `struct gcn_epilogue` (include/gcn_spmm.h)."""
+    _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32),
+                ("dropout_p", ctypes.c_float), ("seed", ctypes.c_uint64)]
+
+
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
 EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan_fill_host",
-           "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_csr_transpose_host")
+           "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_spmm_csr_ep",
+           "gcn_relu_dropout_backward", "gcn_csr_transpose_host")
 
 _lib = None
 
@@ -73,6 +80,15 @@ def lib():
                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
                                ctypes.c_void_p]
+    L.gcn_spmm_csr_ep.restype = ctypes.c_int
+    L.gcn_spmm_csr_ep.argtypes = [ctypes.POINTER(GcnCsrPlan), ctypes.c_int, ctypes.c_void_p,
+                                  ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.POINTER(GcnEpilogue), ctypes.c_void_p, ctypes.c_size_t,
+                                  ctypes.c_void_p]
+    L.gcn_relu_dropout_backward.restype = ctypes.c_int
+    L.gcn_relu_dropout_backward.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_float,
+                                            ctypes.c_void_p]
     L.gcn_csr_transpose_host.restype = ctypes.c_int
     L.gcn_csr_transpose_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,

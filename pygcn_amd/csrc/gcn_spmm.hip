@@ -73,6 +73,9 @@ struct KParams {
     int32_t n_long;
     int32_t long_thresh;
     int32_t relu;
+    uint32_t drop_thresh;   // keep an element iff its 32 random bits >= drop_thresh (0: no dropout)
+    float drop_scale;       // 1 / (1 - p)
+    uint32_t seed_lo, seed_hi;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -146,7 +149,48 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// bias add + ReLU + conversion + store of one output row segment held as VEC floats per lane
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the dropout mask of element (row, f)
+// depends only on (seed, row, f) — never on which kernel variant, vector width, wave or launch
+// produced the row.  Element (row, f) uses word f & 3 of philox(counter = (row_lo, row_hi, f >> 2,
+// 0), key = seed).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <int VEC>
+__device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int f, float (&o)[VEC])
+{
+    uint32_t r[4];
+    if (VEC == 1) {
+        philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(f >> 2), 0u, p.seed_lo,
+                      p.seed_hi, r);
+        o[0] = (r[f & 3] >= p.drop_thresh) ? o[0] * p.drop_scale : 0.f;
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)((f >> 2) + q), 0u,
+                          p.seed_lo, p.seed_hi, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                o[4 * q + i] = (r[i] >= p.drop_thresh) ? o[4 * q + i] * p.drop_scale : 0.f;
+        }
+    }
+}
+
+// bias add + ReLU + dropout + conversion + store of one output row segment (VEC floats per lane)
 template <typename T, int VEC>
 __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
                                           const float (&acc)[VEC], const float (&bias)[VEC])
@@ -157,6 +201,7 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         o[i] = acc[i] + bias[i];
         if (p.relu) o[i] = fmaxf(o[i], 0.f);
     }
+    if (p.drop_thresh != 0u) apply_dropout<VEC>(p, row, f, o);   // wave-uniform branch
     if (act) {
         T *dst = (T *)p.C + row * p.ldc + f;
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
@@ -414,6 +459,29 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
 }
 
 // ------------------------------------------------------------------------------------------
+// backward of the fused ReLU + inverted-dropout epilogue: out = relu(z) * mask / (1 - p), so
+// out > 0 <=> (z > 0 and kept), and grad_z = grad_out * scale * [out > 0].  One streaming pass,
+// 16 B per lane, grid-stride (HBM-bound: 2 reads + 1 write per element).
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T *__restrict__ grad_out,
+                                                               const T *__restrict__ out,
+                                                               T *__restrict__ grad_pre,
+                                                               int64_t n_units, float scale)
+{
+    typedef typename Elem<T, VEC>::Raw Raw;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_units; i += stride) {
+        float g[VEC], o[VEC];
+        Elem<T, VEC>::unpack(((const Raw *)grad_out)[i], g);
+        Elem<T, VEC>::unpack(((const Raw *)out)[i], o);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g[k] = o[k] > 0.f ? g[k] * scale : 0.f;
+        ((Raw *)grad_pre)[i] = Elem<T, VEC>::pack(g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPR>
@@ -610,32 +678,37 @@ size_t gcn_spmm_workspace_bytes(const gcn_csr_plan *plan, int64_t F)
     return (size_t)plan->n_chunks * (size_t)F * sizeof(float);
 }
 
-int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
-                 int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
-                 size_t workspace_bytes, void *stream)
+int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
+                    int64_t ldc, int64_t F, const gcn_epilogue *ep, void *workspace,
+                    size_t workspace_bytes, void *stream)
 {
-    if (plan == nullptr) return fail(GCN_E_BADARG, "gcn_spmm_csr: plan is NULL");
+    const float *bias = ep ? ep->bias : nullptr;
+    const int relu = ep ? ep->relu : 0;
+    const float drop_p = ep ? ep->dropout_p : 0.f;
+    if (!(drop_p >= 0.f && drop_p < 1.f))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: dropout_p must be in [0, 1)");
+    if (plan == nullptr) return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: plan is NULL");
     if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: unknown dtype");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: unknown dtype");
     if (plan->n_rows < 0 || plan->n_cols < 0 || plan->nnz < 0 || F < 0 || F > INT32_MAX)
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: negative size");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: negative size");
     if (plan->n_rows == 0 || F == 0) return 0;
     if (C == nullptr || (B == nullptr && plan->nnz > 0))
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: B or C is NULL");
-    if (ldb < F || ldc < F) return fail(GCN_E_BADARG, "gcn_spmm_csr: ldb/ldc smaller than F");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: B or C is NULL");
+    if (ldb < F || ldc < F) return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: ldb/ldc smaller than F");
     if (ldb * 4 >= ((int64_t)1 << 32))
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: row stride of B must be below 4 GiB");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: row stride of B must be below 4 GiB");
     if (plan->rowptr == nullptr || plan->items == nullptr ||
         (plan->nnz > 0 && (plan->col == nullptr || plan->val == nullptr)))
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: plan has NULL arrays");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: plan has NULL arrays");
     if (plan->n_chunks > 0 && (plan->chunk_row == nullptr || plan->chunk_e0 == nullptr ||
                                plan->long_row == nullptr || plan->long_chunk0 == nullptr))
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: plan has long rows but NULL chunk arrays");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: plan has long rows but NULL chunk arrays");
     if (plan->n_items + plan->n_chunks >= INT32_MAX || plan->n_long >= INT32_MAX)
-        return fail(GCN_E_BADARG, "gcn_spmm_csr: schedule too large");
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: schedule too large");
     const size_t need = gcn_spmm_workspace_bytes(plan, F);
     if (need > 0 && (workspace == nullptr || workspace_bytes < need))
-        return fail(GCN_E_WORKSPACE, "gcn_spmm_csr: workspace too small");
+        return fail(GCN_E_WORKSPACE, "gcn_spmm_csr_ep: workspace too small");
 
     KParams kp;
     kp.rowptr = plan->rowptr;
@@ -658,9 +731,67 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     kp.n_long = (int32_t)plan->n_long;
     kp.long_thresh = plan->long_thresh > 0 ? plan->long_thresh : kDefaultLongThresh;
     kp.relu = relu ? 1 : 0;
+    // keep iff rand32 >= p * 2^32  (p = 0 -> threshold 0 -> dropout off)
+    kp.drop_thresh = drop_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)drop_p * 4294967296.0)
+                                  : 0u;
+    if (drop_p > 0.f && kp.drop_thresh == 0u) kp.drop_thresh = 1u;
+    kp.drop_scale = 1.f / (1.f - drop_p);
+    kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
+    kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GCN_DTYPE_F32) return spmm_typed<float, 4>(plan, kp, s);
     return spmm_typed<bf16_t, 8>(plan, kp, s);
+}
+
+int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb, void *C,
+                 int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
+                 size_t workspace_bytes, void *stream)
+{
+    gcn_epilogue ep;
+    ep.bias = bias;
+    ep.relu = relu;
+    ep.dropout_p = 0.f;
+    ep.seed = 0;
+    return gcn_spmm_csr_ep(plan, dtype, B, ldb, C, ldc, F, &ep, workspace, workspace_bytes, stream);
+}
+
+int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, void *grad_pre,
+                              int64_t n_elems, float scale, void *stream)
+{
+    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward: unknown dtype");
+    if (n_elems < 0) return fail(GCN_E_BADARG, "gcn_relu_dropout_backward: negative size");
+    if (n_elems == 0) return 0;
+    if (grad_out == nullptr || out == nullptr || grad_pre == nullptr)
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward: NULL pointer");
+    const int64_t per = dtype == GCN_DTYPE_F32 ? 4 : 8;           // elements per 16-byte lane
+    const bool vec = (n_elems % per == 0) && (((uintptr_t)grad_out | (uintptr_t)out |
+                                                (uintptr_t)grad_pre) % 16 == 0);
+    const int64_t n_units = vec ? n_elems / per : n_elems;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_units + 255) / 256, 256 * 8 * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == GCN_DTYPE_F32) {
+        if (vec)
+            hipLaunchKernelGGL((relu_dropout_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s,
+                               (const float *)grad_out, (const float *)out, (float *)grad_pre,
+                               n_units, scale);
+        else
+            hipLaunchKernelGGL((relu_dropout_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s,
+                               (const float *)grad_out, (const float *)out, (float *)grad_pre,
+                               n_units, scale);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((relu_dropout_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s,
+                               (const bf16_t *)grad_out, (const bf16_t *)out, (bf16_t *)grad_pre,
+                               n_units, scale);
+        else
+            hipLaunchKernelGGL((relu_dropout_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s,
+                               (const bf16_t *)grad_out, (const bf16_t *)out, (bf16_t *)grad_pre,
+                               n_units, scale);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "relu_dropout_backward launch");
+    return 0;
 }
 
 int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,

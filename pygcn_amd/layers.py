@@ -20,7 +20,7 @@ from torch.nn.parameter import Parameter
 if not __package__:   # imported flat, the reference's convention (`from layers import ...`)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
-from pygcn_amd.spmm import DenseMMFunction, SpMMFunction  # noqa: E402
+from pygcn_amd.spmm import DenseMMFunction, SpMMFunction, next_dropout_seed  # noqa: E402
 from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
@@ -46,27 +46,54 @@ class GraphConvolution(Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj, relu=False):
+    def forward(self, input, adj, relu=False, dropout=0.0):
         """support = input @ W (MFMA GEMM via torch.mm), output = adj @ support (HIP SpMM),
         + bias fused into the SpMM's store.  `adj`: CSRGraph, torch sparse COO/CSR (converted
         once and cached on the tensor), a ShardedGraph (multi-GPU row block), or a dense [N,N]
         tensor (the fork's live scripts pass a dense adjacency, utils.py:124-131 — torch.spmm is
         a dense GEMM there, and so is this).
 
-        `relu=True` (an extension; default is the reference's behaviour) applies the ReLU that
-        follows the layer in the model (models.py:48 upstream) inside the kernel's store."""
+        `relu=True` / `dropout=p` (extensions; the defaults are the reference's behaviour) apply
+        the ReLU and the training-mode dropout that follow the layer in the model (models.py:48,50
+        upstream) inside the kernel's store; `dropout` requires `relu`."""
+        if input.dim() == 3:
+            out = self._forward_batched(input, adj, relu)
+            return torch.nn.functional.dropout(out, dropout, True) if dropout > 0.0 else out
+        seed = next_dropout_seed() if dropout > 0.0 else 0
         if isinstance(adj, ShardedGraph):
-            # row-block shard of a multi-GPU run: all-gather + local HIP SpMM (pygcn_amd/sharded.py)
+            # row-block shard of a multi-GPU run: exchange + local HIP SpMM (pygcn_amd/sharded.py)
             return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
-                                             self.bias, relu)
+                                             self.bias, relu, dropout, seed)
         _require_cuda(input, "input")
         _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
         if isinstance(adj, torch.Tensor) and adj.layout == torch.strided:
             output = torch.mm(adj, torch.mm(input, self.weight))
             output = output + self.bias if self.bias is not None else output
-            return torch.relu(output) if relu else output
+            output = torch.relu(output) if relu else output
+            return torch.nn.functional.dropout(output, dropout, True) if dropout > 0.0 else output
         support = DenseMMFunction.apply(input, self.weight)
-        return SpMMFunction.apply(as_graph(adj), support, self.bias, relu)
+        return SpMMFunction.apply(as_graph(adj), support, self.bias, relu, dropout, seed)
+
+    def _forward_batched(self, input, adj, relu):
+        """k samples over the same graph in ONE sparse product.  The fork runs
+        its GCN once per sample in a Python loop ("cannot batch yet", reference
+        pygcn/models.py:343-349); here input is [k, N, Fin]: the k supports are laid side by side
+        as [N, k·Fout], so every gathered row of the dense operand is k·Fout wide (k launches of
+        narrow rows become one launch of wide rows), and the result is returned as [k, N, Fout]."""
+        k, n, _ = input.shape
+        support = torch.matmul(input, self.weight)                       # [k, N, Fout]
+        wide = support.permute(1, 0, 2).reshape(n, k * self.out_features)
+        bias = self.bias.repeat(k) if self.bias is not None else None
+        if isinstance(adj, torch.Tensor) and adj.layout == torch.strided:
+            out = torch.mm(adj, wide)
+            out = out + bias if bias is not None else out
+            out = torch.relu(out) if relu else out
+        elif isinstance(adj, ShardedGraph):
+            out = ShardedSpMMFunction.apply(adj, wide.contiguous(), bias, relu)
+        else:
+            _require_cuda(input, "input")
+            out = SpMMFunction.apply(as_graph(adj), wide, bias, relu)
+        return out.view(n, k, self.out_features).permute(1, 0, 2)
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' \

@@ -25,10 +25,10 @@ class GCN(nn.Module):
         self.dropout = dropout
 
     def forward(self, x, adj):
-        x = self.gc1(x, adj, relu=True)          # F.relu(gc1(x, adj)) with the ReLU fused in-kernel
-        x = F.dropout(x, self.dropout, training=self.training)
+        # F.dropout(F.relu(gc1(x, adj)), p, training) with ReLU and dropout fused into the SpMM store
+        x = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
         x = self.gc2(x, adj)
-        return F.log_softmax(x, dim=1)
+        return F.log_softmax(x, dim=-1)   # dim=1 for the reference's [N, C]; last dim if batched
 
 
 class GCNStack(nn.Module):

@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 from .graph import CSRGraph
-from .spmm import spmm_csr
+from .spmm import relu_dropout_backward, spmm_csr
 
 
 def partition_rows(rowptr, world):
@@ -212,7 +212,7 @@ class ShardedGraph:
         dist.all_gather_into_tensor(out, slot, group=self.group)   # in-place form
         return out
 
-    def product(self, local, transpose=False, bias=None, relu=False):
+    def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0):
         ev = None
         if self.timing is not None and local.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -221,8 +221,9 @@ class ShardedGraph:
             gathered = (self.halo_t if transpose else self.halo).exchange(local)
         else:
             gathered = self.all_gather_rows(local)
+        kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
         out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
-                         tag="bwd_local" if transpose else "fwd_local")
+                         tag="bwd_local" if transpose else "fwd_local", **kw)
         if ev is not None:
             ev[1].record()
             self.timing.append(("bwd" if transpose else "fwd", ev[0], ev[1]))
@@ -242,11 +243,15 @@ class ShardedSpMMFunction(torch.autograd.Function):
     """out_r = Â_r · allgather(support);  grad_support_r = (Âᵀ)_r · allgather(grad_out)."""
 
     @staticmethod
-    def forward(ctx, sg, support_local, bias, relu=False):
+    def forward(ctx, sg, support_local, bias, relu=False, dropout_p=0.0, seed=0):
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
         ctx.sg = sg
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        out = sg.product(support_local, transpose=False, bias=bias, relu=relu)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        out = sg.product(support_local, transpose=False, bias=bias, relu=relu,
+                         dropout_p=dropout_p, seed=seed)
         if relu:
             ctx.save_for_backward(out)
         return out
@@ -256,12 +261,15 @@ class ShardedSpMMFunction(torch.autograd.Function):
         grad_support = grad_bias = None
         if ctx.relu:
             (out,) = ctx.saved_tensors
-            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0)
+            if grad_out.is_cuda:
+                grad_out = relu_dropout_backward(grad_out, out, ctx.scale)
+            else:   # gloo/CPU logic tests only (tests/ supply the CPU local product)
+                grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0) * ctx.scale
         if ctx.needs_input_grad[1]:
             grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.sum(0)          # partial: summed over ranks by allreduce_grads
-        return None, grad_support, grad_bias, None
+        return None, grad_support, grad_bias, None, None, None
 
 
 class ShardedGCN(torch.nn.Module):

@@ -26,8 +26,10 @@ def set_timing_records(records):
     _timing_records = records
 
 
-def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd"):
-    """C = A · B (+ bias, ReLU) on the current HIP stream; A is a CSRGraph, B dense [n_cols, F]."""
+def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0):
+    """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
+    B dense [n_cols, F].  The epilogue order is that of the reference model: bias
+    (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -61,29 +63,57 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd"):
         if rec is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = L.gcn_spmm_csr(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
-                            out.data_ptr(), out.stride(0), F,
-                            bias.data_ptr() if bias is not None else None, int(bool(relu)),
-                            ws.data_ptr() if ws is not None else None, ws_bytes, stream)
+        ep = _native.GcnEpilogue(bias.data_ptr() if bias is not None else None, int(bool(relu)),
+                                 float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+        rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
+                               out.data_ptr(), out.stride(0), F, ep,
+                               ws.data_ptr() if ws is not None else None, ws_bytes, stream)
         if rec is not None:
             ev1.record()
             rec.append((tag, ev0, ev1, graph))
-    _native.check(rc, "gcn_spmm_csr")
+    _native.check(rc, "gcn_spmm_csr_ep")
     return out
 
 
+def relu_dropout_backward(grad_out, out, scale=1.0):
+    """grad_pre = out > 0 ? grad_out * scale : 0 in one streaming HIP pass
+    (C-ABI gcn_relu_dropout_backward): backward of the fused ReLU (+ dropout) epilogue."""
+    _require_cuda(grad_out, "grad_out")
+    if grad_out.dtype not in _DTYPES or out.dtype != grad_out.dtype or out.shape != grad_out.shape:
+        raise RuntimeError("relu_dropout_backward: dtype/shape mismatch")
+    grad_out, out = grad_out.contiguous(), out.contiguous()
+    res = torch.empty_like(grad_out)
+    with torch.cuda.device(grad_out.device):
+        rc = _native.lib().gcn_relu_dropout_backward(
+            _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr(), res.data_ptr(),
+            grad_out.numel(), float(scale), torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_relu_dropout_backward")
+    return res
+
+
+def next_dropout_seed():
+    """64-bit seed drawn from torch's default CPU generator: reproducible under
+    torch.manual_seed, no device synchronisation."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
 class SpMMFunction(torch.autograd.Function):
-    """out = [relu](A · B [+ bias]);  grad_B = A^T · grad_pre;  grad_bias = column sums of
-    grad_pre, where grad_pre = grad_out (masked by out > 0 when the ReLU was fused).
+    """out = dropout(relu(A · B + bias)) with every stage optional and fused into the kernel's
+    store;  grad_B = A^T · grad_pre;  grad_bias = column sums of grad_pre, where
+    grad_pre = grad_out, masked and scaled through `out > 0` when ReLU (+ dropout) was fused.
     `adj` never receives a gradient (it is a loaded constant in the reference: train.py:80,123).
-    Only the graph handle (and the output, for a fused ReLU) is kept for backward — not B."""
+    Only the graph handle (and the output, for a fused ReLU) is kept for backward — not B and no
+    dropout mask."""
 
     @staticmethod
-    def forward(ctx, graph, B, bias, relu=False):
+    def forward(ctx, graph, B, bias, relu=False, dropout_p=0.0, seed=0):
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        out = spmm_csr(graph, B, bias=bias, relu=relu)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        out = spmm_csr(graph, B, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
         if relu:
             ctx.save_for_backward(out)
         return out
@@ -93,12 +123,12 @@ class SpMMFunction(torch.autograd.Function):
         grad_B = grad_bias = None
         if ctx.relu:
             (out,) = ctx.saved_tensors
-            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0)
+            grad_out = relu_dropout_backward(grad_out, out, ctx.scale)
         if ctx.needs_input_grad[1]:
             grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_out.sum(0)
-        return None, grad_B, grad_bias, None
+        return None, grad_B, grad_bias, None, None, None
 
 
 class DenseMMFunction(torch.autograd.Function):
