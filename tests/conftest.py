@@ -13,6 +13,11 @@ for p in (ROOT, GOLDEN):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # safety net for a fresh checkout: build the HIP library in-tree (hipcc cross-compiles gfx950
+    # without a GPU); normally __graft_entry__.build() has already done it
+    from pygcn_amd import build as native_build
+    if native_build.needs_build():
+        native_build.build(verbose=False)
 
 
 def load_golden(name):
