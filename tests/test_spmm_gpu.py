@@ -411,3 +411,45 @@ def test_fused_dropout_autograd_and_model(oracle, dev):
     torch.manual_seed(9)
     r2 = m(xg.detach(), g)
     assert torch.equal(r1, r2)     # reproducible under torch.manual_seed
+
+
+def test_randomized_shapes_and_schedules(oracle, dev):
+    """40 seeded random problems over shape, skew, feature width, dtype of rowptr, epilogue and
+    the schedule knobs of the ABI (item_cost / long_thresh down to values that make almost every
+    row a chunked long row or a single-row item)."""
+    from pygcn_amd import CSRGraph, spmm_csr
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n_rows = int(rng.integers(1, 700))
+        n_cols = int(rng.integers(1, 700))
+        F = int(rng.choice([1, 2, 5, 8, 31, 32, 48, 64, 96, 128, 132, 256, 384, 515]))
+        deg = rng.poisson(rng.choice([0.3, 2, 9]), size=n_rows)
+        for _ in range(int(rng.integers(0, 4))):
+            deg[rng.integers(0, n_rows)] = int(rng.integers(50, 1500))
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        nnz = int(rowptr[-1])
+        col = rng.integers(0, n_cols, size=nnz).astype(np.int32)
+        val = rng.standard_normal(nnz).astype(np.float32)
+        a = oracle.CSR(rowptr, col, val, (n_rows, n_cols))
+        kw = dict(item_cost=int(rng.choice([0, 1, 8, 33, 200])),
+                  long_thresh=int(rng.choice([0, 1, 4, 37, 600])))
+        rp_t = torch.from_numpy(rowptr if case % 3 == 0 else rowptr.astype(np.int32))
+        g = CSRGraph(rp_t.to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                     (n_rows, n_cols), **kw)
+        B = gin.dense((n_cols, F), 5000 + case)
+        bias = gin.dense((F,), 6000 + case) if case % 2 else None
+        relu = bool(case % 4 == 1)
+        ref = a.matmul(B)
+        if bias is not None:
+            ref = ref + bias
+        if relu:
+            ref = np.maximum(ref, 0)
+        out = spmm_csr(g, torch.from_numpy(B).to(dev),
+                       bias=None if bias is None else torch.from_numpy(bias).to(dev), relu=relu)
+        scale = max(np.abs(a.matmul(B)).max(), 1e-30) if nnz else 1.0
+        err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max() if ref.size else 0.0
+        assert err <= 1e-5 * max(scale, np.abs(ref).max() if ref.size else 0.0), \\
+            f"case {case}: n={n_rows}x{n_cols} F={F} {kw} err {err:.3e}"
+        G = gin.dense((n_rows, F), 7000 + case)
+        out_t = spmm_csr(g.t(), torch.from_numpy(G).to(dev))
+        assert_normwise(out_t.cpu(), a.t_matmul(G), TOL, f"case {case} transpose")
