@@ -448,8 +448,8 @@ def test_randomized_shapes_and_schedules(oracle, dev):
                        bias=None if bias is None else torch.from_numpy(bias).to(dev), relu=relu)
         scale = max(np.abs(a.matmul(B)).max(), 1e-30) if nnz else 1.0
         err = np.abs(out.cpu().numpy().astype(np.float64) - ref).max() if ref.size else 0.0
-        assert err <= 1e-5 * max(scale, np.abs(ref).max() if ref.size else 0.0), \\
-            f"case {case}: n={n_rows}x{n_cols} F={F} {kw} err {err:.3e}"
+        bound = 1e-5 * max(scale, np.abs(ref).max() if ref.size else 0.0)
+        assert err <= bound, f"case {case}: n={n_rows}x{n_cols} F={F} {kw} err {err:.3e}"
         G = gin.dense((n_rows, F), 7000 + case)
         out_t = spmm_csr(g.t(), torch.from_numpy(G).to(dev))
         assert_normwise(out_t.cpu(), a.t_matmul(G), TOL, f"case {case} transpose")
