@@ -424,18 +424,118 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 
     const int it = item - p.n_chunks;
     const int ra = p.items[2 * it], rb = p.items[2 * it + 1];
+    const int nr = rb - ra;
     if (p.bias != nullptr && act) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
     }
-    int64_t e0 = (int64_t)rp[ra];
-    for (int r = ra; r < rb; ++r) {
-        const int64_t e1 = (int64_t)rp[r + 1];
+    constexpr int G = kWave / LPR;
+    const int64_t ea = (int64_t)rp[ra];
+    const int rel_end = (lane < nr) ? (int)((int64_t)rp[ra + 1 + lane] - ea) : 0;
+    const int ne = readlane_i(rel_end, nr - 1);
+
+    if (G == 1 || nr == 1 || ne > kWave) {
+        // one row at a time, its stored entries split over the G lane groups
+        int64_t e0 = ea;
+        for (int r = ra; r < rb; ++r) {
+            const int64_t e1 = (int64_t)rp[r + 1];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+            narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
+            store_out<T, VEC>(p, (int64_t)r, f, act && g == 0, acc, bias);
+            e0 = e1;
+        }
+        return;
+    }
+
+    // ---- row-per-group: each lane group owns a different SHORT row of the item, so G*RU rows
+    // are in flight for the accumulator cost of RU rows and no cross-lane reduction is needed.
+    // Row ends and the (col, val) tile of the item (<= 64 entries) sit in lanes and are read
+    // with ds_bpermute: no dependent memory round trip per row.
+    typedef typename Elem<T, VEC>::Raw Raw;
+    constexpr int RU = (G >= 8) ? 2 : 4;     // rounds in flight
+    constexpr int UU = 2;                     // entries per row per step
+    constexpr int kShort = 8;                 // rows longer than this take the edge-split path
+    const int64_t ldb_bytes = p.ldb * (int64_t)sizeof(T);
+    int cv = 0;
+    float vv = 0.f;
+    if (lane < ne) {
+        cv = p.col[ea + lane];
+        vv = p.val[ea + lane];
+    }
+    const int up = __shfl_up(rel_end, 1, kWave);
+    const int rel_start = (lane == 0) ? 0 : up;
+    unsigned long long medium = __ballot(lane < nr && rel_end - rel_start > kShort);
+
+    for (int q0 = 0; q0 < nr; q0 += G * RU) {
+        int e0[RU], e1[RU], row[RU];
+        float a2[RU][VEC];
+#pragma unroll
+        for (int ru = 0; ru < RU; ++ru) {
+            const int r = q0 + ru * G + g;
+            const int s0 = __shfl(rel_start, r & (kWave - 1), kWave);
+            const int s1 = __shfl(rel_end, r & (kWave - 1), kWave);
+            const bool mine = r < nr && s1 - s0 <= kShort;
+            row[ru] = mine ? r : -1;
+            e0[ru] = s0;
+            e1[ru] = mine ? s1 : s0;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) a2[ru][i] = 0.f;
+        }
+        for (int j = 0; j < kShort; j += UU) {
+            bool more = false;
+#pragma unroll
+            for (int ru = 0; ru < RU; ++ru) more |= (e0[ru] + j < e1[ru]);
+            if (!__any(more)) break;
+            Raw x[RU][UU];
+            float av[RU][UU];
+#pragma unroll
+            for (int ru = 0; ru < RU; ++ru) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const int idx = e0[ru] + j + u;
+                    const bool ok = idx < e1[ru];
+                    const int c = __shfl(cv, idx & (kWave - 1), kWave);
+                    const float a = __shfl(vv, idx & (kWave - 1), kWave);
+                    av[ru][u] = ok ? a : 0.f;
+                    Raw z = {};
+                    x[ru][u] = z;
+                    if (ok)
+                        x[ru][u] = *(const Raw *)((const char *)p.B + (int64_t)c * ldb_bytes +
+                                                  ld_off);
+                }
+            }
+#pragma unroll
+            for (int ru = 0; ru < RU; ++ru) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    if (e0[ru] + j + u < e1[ru]) {   // skip: never multiply an unloaded slot
+                        float xf[VEC];
+                        Elem<T, VEC>::unpack(x[ru][u], xf);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i)
+                            a2[ru][i] = fmaf(av[ru][u], xf[i], a2[ru][i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ru = 0; ru < RU; ++ru) {
+            if (row[ru] >= 0)
+                store_out<T, VEC>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
+        }
+    }
+
+    // ---- the item's medium rows (kShort < entries <= long_thresh): entries split over the
+    // lane groups, wavefront shuffle reduction
+    while (medium) {
+        const int rr = __builtin_ctzll(medium);
+        medium &= medium - 1;
+        const int s0 = readlane_i(rel_start, rr), s1 = readlane_i(rel_end, rr);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
-        store_out<T, VEC>(p, (int64_t)r, f, act && g == 0, acc, bias);
-        e0 = e1;
+        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc);
+        store_out<T, VEC>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
     }
 }
 
