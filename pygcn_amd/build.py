@@ -27,6 +27,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
            "-I", os.path.join(ROOT, "include"), "-o", OUT + ".tmp", SRC]
+    cmd[1:1] = os.environ.get("PYGCN_HIPCC_FLAGS", "").split()    # tuning experiments only
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -453,9 +453,18 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     // Row ends and the (col, val) tile of the item (<= 64 entries) sit in lanes and are read
     // with ds_bpermute: no dependent memory round trip per row.
     typedef typename Elem<T, VEC>::Raw Raw;
-    constexpr int RU = (G >= 8) ? 2 : 4;     // rounds in flight
-    constexpr int UU = 2;                     // entries per row per step
-    constexpr int kShort = 8;                 // rows longer than this take the edge-split path
+#ifndef GCN_RU      // tuned on MI355X (C4 graph): RU 2 / UU 2 / kShort 8 beat 1,3,4 / 1,4 / 4,16,32
+#define GCN_RU 2
+#endif
+#ifndef GCN_UU
+#define GCN_UU 2
+#endif
+#ifndef GCN_KSHORT
+#define GCN_KSHORT 8
+#endif
+    constexpr int RU = GCN_RU;                // rounds in flight
+    constexpr int UU = GCN_UU;                // entries per row per step
+    constexpr int kShort = GCN_KSHORT;        // rows longer than this take the edge-split path
     const int64_t ldb_bytes = p.ldb * (int64_t)sizeof(T);
     int cv = 0;
     float vv = 0.f;
