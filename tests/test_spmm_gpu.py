@@ -453,3 +453,29 @@ def test_randomized_shapes_and_schedules(oracle, dev):
         G = gin.dense((n_rows, F), 7000 + case)
         out_t = spmm_csr(g.t(), torch.from_numpy(G).to(dev))
         assert_normwise(out_t.cpu(), a.t_matmul(G), TOL, f"case {case} transpose")
+
+
+def test_bf16_model_end_to_end(oracle, dev):
+    """Config C5 numerics through the whole layer stack: bf16 parameters / activations, fp32
+    adjacency values and accumulation; forward and backward stay within bf16 rounding of the fp32
+    run (2^-6 normwise on activations after two layers, 2^-4 on gradients)."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.utils import rmat_graph
+    n, F = 20000, 128
+    rowptr, col, val = rmat_graph(n, 200000, seed=3, device="cpu")
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, F), 1)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(2).integers(0, F, n)).to(dev)
+    torch.manual_seed(5)
+    m32 = GCN(F, F, F, dropout=0.0).to(dev)
+    m16 = GCN(F, F, F, dropout=0.0).to(dev).to(torch.bfloat16)
+    m16.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()})
+    out32 = m32(x, g)
+    out16 = m16(x.to(torch.bfloat16), g)
+    assert out16.dtype == torch.bfloat16
+    torch.nn.functional.nll_loss(out32, y).backward()
+    torch.nn.functional.nll_loss(out16.float(), y).backward()
+    assert_normwise(out16.float().detach().cpu(), out32.detach().cpu().numpy(), 2.0 ** -6, "logp")
+    for (k, p16), (_, p32) in zip(m16.named_parameters(), m32.named_parameters()):
+        assert p16.grad.dtype == torch.bfloat16
+        assert_normwise(p16.grad.float().cpu(), p32.grad.cpu().numpy(), 2.0 ** -4, k + ".grad")
