@@ -34,7 +34,10 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
+#ifndef GCN_WPB
+#define GCN_WPB 4
+#endif
+constexpr int kWavesPerBlock = GCN_WPB;
 constexpr int kDefaultItemCost = 64;
 constexpr int kDefaultLongThresh = 256;
 
