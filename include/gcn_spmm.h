@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 2
+#define GCN_ABI_VERSION 3
 
 /*
  * A CSR adjacency (or its transpose) plus the static launch schedule built for it once.
@@ -158,6 +158,29 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
 int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,
                            const float *val, int64_t n_rows, int64_t n_cols, void *rowptr_t,
                            int32_t *col_t, float *val_t);
+
+/*
+ * Device-side ingest — everything below runs on `stream`, never allocates.
+ *
+ * gcn_csr_transpose_device: CSR(A) -> CSR(A^T) entirely on the DEVICE (stable radix sort by
+ * column carrying (source row, value)); each row of A^T lists its entries in increasing
+ * source-row order, exactly like gcn_csr_transpose_host.  All array arguments are DEVICE
+ * pointers; rowptr_t has the width of rowptr.  Scratch: gcn_csr_transpose_workspace_bytes().
+ * Replaces the transposed view PyTorch re-derives on every backward call of torch.spmm
+ * (autograd of pygcn/layers.py:34).
+ */
+size_t gcn_csr_transpose_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int gcn_csr_transpose_device(const void *rowptr, int rowptr_is64, const int32_t *col,
+                             const float *val, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                             void *rowptr_t, int32_t *col_t, float *val_t, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
+/*
+ * val <- D^-1 · val in place on the DEVICE: every stored entry is divided by the sum of its row;
+ * rows that sum to 0 stay 0.  The reference's `normalize(mx)` (pygcn/utils.py:390-397).
+ */
+int gcn_row_normalize_device(const void *rowptr, int rowptr_is64, float *val, int64_t n_rows,
+                             void *stream);
 
 #ifdef __cplusplus
 }

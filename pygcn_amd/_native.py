@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 2
+GCN_ABI_VERSION = 3
 GCN_DTYPE_F32 = 0
 GCN_DTYPE_BF16 = 1
 
@@ -41,7 +41,9 @@ class GcnEpilogue(ctypes.Structure):
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
 EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan_fill_host",
            "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_spmm_csr_ep",
-           "gcn_relu_dropout_backward", "gcn_csr_transpose_host")
+           "gcn_relu_dropout_backward", "gcn_csr_transpose_host",
+           "gcn_csr_transpose_workspace_bytes", "gcn_csr_transpose_device",
+           "gcn_row_normalize_device")
 
 _lib = None
 
@@ -93,6 +95,17 @@ def lib():
     L.gcn_csr_transpose_host.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.gcn_csr_transpose_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_csr_transpose_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.gcn_csr_transpose_device.restype = ctypes.c_int
+    L.gcn_csr_transpose_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p]
+    L.gcn_row_normalize_device.restype = ctypes.c_int
+    L.gcn_row_normalize_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_void_p]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "gcn_spmm.hip")
+SRCS = [os.path.join(HERE, "csrc", "gcn_spmm.hip"), os.path.join(HERE, "csrc", "gcn_ingest.hip")]
 OUT = os.path.join(HERE, "csrc", "libgcn_spmm.so")
 ARCH = "gfx950"
 
@@ -17,7 +17,7 @@ ARCH = "gfx950"
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [SRC, os.path.join(ROOT, "include", "gcn_spmm.h")]
+    deps = SRCS + [os.path.join(ROOT, "include", "gcn_spmm.h")]
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
-           "-I", os.path.join(ROOT, "include"), "-o", OUT + ".tmp", SRC]
+           "-I", os.path.join(ROOT, "include"), "-o", OUT + ".tmp"] + SRCS
     cmd[1:1] = os.environ.get("PYGCN_HIPCC_FLAGS", "").split()    # tuning experiments only
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

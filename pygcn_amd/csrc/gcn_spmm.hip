@@ -738,6 +738,13 @@ int plan_walk(const IdxT *rp, int64_t n_rows, int item_cost, int long_thresh, in
 
 }   // namespace
 
+// shared with gcn_ingest.hip
+int gcn_internal_fail(int code, const char *msg) { return fail(code, msg); }
+int gcn_internal_fail_hip(int hip_error, const char *where)
+{
+    return fail_hip((hipError_t)hip_error, where);
+}
+
 extern "C" {
 
 int gcn_abi_version(void) { return GCN_ABI_VERSION; }

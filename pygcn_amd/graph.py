@@ -158,29 +158,43 @@ class CSRGraph:
 
     # ------------------------------------------------------------------ transpose (for backward)
     def t(self):
-        """CSR(A^T), built once.  Within each row of A^T the entries are in increasing source-row
-        order (stable sort by column), so backward sums are deterministic."""
+        """CSR(A^T), built once on the device by the native ingest kernel
+        (`gcn_csr_transpose_device`: stable radix sort by column).  Within each row of A^T the
+        entries are in increasing source-row order, so backward sums are deterministic."""
         if self._t is None:
             n_rows, n_cols = self.shape
             dev = self.device
-            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
-            src_row = torch.repeat_interleave(
-                torch.arange(n_rows, device=dev, dtype=torch.int32), deg)
-            _, perm = torch.sort(self.col, stable=True)
-            col_t = src_row[perm]
-            val_t = self.val[perm]
-            del perm, src_row
-            counts = torch.bincount(self.col, minlength=n_cols) if self.nnz else torch.zeros(
-                n_cols, dtype=torch.int64, device=dev)
-            rowptr_t = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(counts, 0, out=rowptr_t[1:])
-            if self.rowptr.dtype == torch.int32:
-                rowptr_t = rowptr_t.to(torch.int32)
+            L = _native.lib()
+            rowptr_t = torch.empty(n_cols + 1, dtype=self.rowptr.dtype, device=dev)
+            col_t = torch.empty(self.nnz, dtype=torch.int32, device=dev)
+            val_t = torch.empty(self.nnz, dtype=torch.float32, device=dev)
+            ws_bytes = L.gcn_csr_transpose_workspace_bytes(n_rows, n_cols, self.nnz)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = L.gcn_csr_transpose_device(
+                    self.rowptr.data_ptr(), int(self.rowptr.dtype == torch.int64),
+                    self.col.data_ptr(), self.val.data_ptr(), n_rows, n_cols, self.nnz,
+                    rowptr_t.data_ptr(), col_t.data_ptr(), val_t.data_ptr(), ws.data_ptr(),
+                    ws_bytes, torch.cuda.current_stream().cuda_stream)
+            _native.check(rc, "gcn_csr_transpose_device")
+            del ws
             g = CSRGraph(rowptr_t, col_t, val_t, (n_cols, n_rows), item_cost=self.item_cost,
                          long_thresh=self.long_thresh)
             g._t = self
             self._t = g
         return self._t
+
+    def row_normalize_(self):
+        """In place D^-1 · A on the device (`gcn_row_normalize_device`): the reference's
+        `normalize(mx)` (pygcn/utils.py:390-397); rows that sum to 0 stay 0.  Invalidates the
+        cached transpose."""
+        with torch.cuda.device(self.device):
+            rc = _native.lib().gcn_row_normalize_device(
+                self.rowptr.data_ptr(), int(self.rowptr.dtype == torch.int64),
+                self.val.data_ptr(), self.shape[0], torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "gcn_row_normalize_device")
+        self._t = None
+        return self
 
     # ------------------------------------------------------------------ misc
     def to_torch_csr(self):

@@ -479,3 +479,48 @@ def test_bf16_model_end_to_end(oracle, dev):
     for (k, p16), (_, p32) in zip(m16.named_parameters(), m32.named_parameters()):
         assert p16.grad.dtype == torch.bfloat16
         assert_normwise(p16.grad.float().cpu(), p32.grad.cpu().numpy(), 2.0 ** -4, k + ".grad")
+
+
+@pytest.mark.parametrize("idx64", [False, True])
+def test_native_transpose_matches_oracle_bitwise(oracle, dev, idx64):
+    """Row f4: CSR(A^T) built on the device equals the oracle's stable counting-sort transpose
+    entry for entry (same order inside every row), for int32 and int64 row pointers."""
+    from pygcn_amd import CSRGraph
+    a = _skewed_csr(oracle, 4000, 2500, 7, seed=12, empties=400,
+                    hubs=((5, 3000), (3999, 1), (0, 600)))
+    rp = a.rowptr if idx64 else a.rowptr.astype(np.int32)
+    g = CSRGraph(torch.from_numpy(rp).to(dev), torch.from_numpy(a.col).to(dev),
+                 torch.from_numpy(a.val).to(dev), a.shape)
+    t = g.t()
+    rp_t, col_t, val_t = oracle.csr_transpose(a.rowptr, a.col, a.val, 2500)
+    assert t.shape == (2500, 4000) and t.rowptr.dtype == g.rowptr.dtype
+    np.testing.assert_array_equal(t.rowptr.cpu().numpy(), rp_t)
+    np.testing.assert_array_equal(t.col.cpu().numpy(), col_t)
+    np.testing.assert_array_equal(t.val.cpu().numpy(), val_t)
+    assert t.t() is g
+    # degenerate: no stored entries
+    e = CSRGraph(torch.zeros(6, dtype=torch.int32, device=dev),
+                 torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, device=dev), (5, 9))
+    assert e.t().rowptr.cpu().tolist() == [0] * 10 and e.t().nnz == 0
+
+
+def test_native_row_normalize_matches_reference_semantics(dev):
+    """`normalize(mx)` of the reference (utils.py:390-397) on the device, in place."""
+    import scipy.sparse as sp
+    from pygcn_amd import CSRGraph
+    from pygcn_amd.utils import normalize
+    rng = np.random.default_rng(4)
+    m = sp.random(3000, 3000, density=0.003, random_state=4, format="csr", dtype=np.float32)
+    m.data = rng.random(m.nnz).astype(np.float32)
+    m = m.tolil()
+    m[7, :] = 0
+    m[11, :200] = rng.random(200)       # a long row
+    m = m.tocsr()
+    m.sort_indices()
+    g = CSRGraph.from_scipy(m, device=dev)
+    g.val[g.rowptr[20].item():g.rowptr[21].item()] = 0.0      # stored zeros: row sums to 0
+    m.data[m.indptr[20]:m.indptr[21]] = 0.0
+    ref = sp.csr_matrix(normalize(m))
+    g.row_normalize_()
+    np.testing.assert_allclose(g.val.cpu().numpy(), ref.data, rtol=2e-6, atol=0)
+    assert not np.isnan(g.val.cpu().numpy()).any()
