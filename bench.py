@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="multi-GPU exchange step: rows a rank references only, or full all-gather")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N>1 code-path rehearsal on ONE GPU: all ranks share cuda:0, collectives "
+                         "go over gloo staged through the host. Not a measurement.")
     return ap.parse_args()
 
 
@@ -135,6 +138,30 @@ def cpu_baseline(rowptr, col, val, n, F, budget_rows):
     return out
 
 
+def _install_host_staging(dist):
+    """--rehearsal only: gloo moves host tensors, so stage device tensors through the host."""
+    import pygcn_amd.sharded as sh
+    real_ag, real_ar, real_p2p = dist.all_gather_into_tensor, dist.all_reduce, sh._p2p_round
+
+    def ag(out, inp, group=None):
+        o, i = out.cpu(), inp.cpu()
+        real_ag(o, i, group=group)
+        out.copy_(o)
+
+    def ar(t, op=dist.ReduceOp.SUM, group=None):
+        c = t.cpu()
+        real_ar(c, op=op, group=group)
+        t.copy_(c)
+
+    def p2p(sends, recvs, group):
+        hs = [(t.cpu(), peer) for t, peer in sends]
+        hr = [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
+        real_p2p(hs, hr, group)
+        for (t, _), (h, _) in zip(recvs, hr):
+            t.copy_(h)
+    dist.all_gather_into_tensor, dist.all_reduce, sh._p2p_round = ag, ar, p2p
+
+
 def main():
     args = parse()
     if args.cpu_baseline_child:
@@ -149,11 +176,16 @@ def main():
                              "(--nproc-per-node N)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 and args.rehearsal:
+        dist.init_process_group("gloo")
+        _install_host_staging(dist)
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
     from pygcn_amd import GCN, CSRGraph, _native
@@ -279,6 +311,8 @@ def main():
             "value": round(gedges, 4), "unit": "GEdge/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            **({"rehearsal": "one GPU shared by all ranks, gloo staged through the host: "
+                             "code-path check only, not a measurement"} if args.rehearsal else {}),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: R-MAT(0.57,0.19,0.19,0.05) {n_total} nodes / "
                                    f"{e} sampled edges -> nnz {nnz_total} (dedupe + I, "
