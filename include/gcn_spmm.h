@@ -38,6 +38,9 @@ extern "C" {
 
 #define GCN_ABI_VERSION 3
 
+#define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
+#define GCN_DEFAULT_LONG_THRESH 1024   /* rows with more stored entries are chunked             */
+
 /*
  * A CSR adjacency (or its transpose) plus the static launch schedule built for it once.
  * All pointers are DEVICE pointers.  The schedule splits the rows of the matrix into
@@ -78,9 +81,9 @@ const char *gcn_last_error(void);
 /*
  * Planner, pass 1: count items / chunks / long rows for a HOST rowptr.
  *   item_cost   : target work per row-batch item, in units of (stored entries + rows); <= 0
- *                 selects the default (64).
+ *                 selects GCN_DEFAULT_ITEM_COST.
  *   long_thresh : rows with more stored entries than this are chunked; <= 0 selects the
- *                 default (256).
+ *                 GCN_DEFAULT_LONG_THRESH.
  */
 int gcn_plan_count_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
                         int32_t item_cost, int32_t long_thresh, int64_t *n_items,

@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
 GCN_ABI_VERSION = 3
+GCN_DEFAULT_ITEM_COST = 64
+GCN_DEFAULT_LONG_THRESH = 1024
 GCN_DTYPE_F32 = 0
 GCN_DTYPE_BF16 = 1
 

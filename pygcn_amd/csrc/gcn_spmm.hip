@@ -38,8 +38,8 @@ constexpr int kWave = 64;
 #define GCN_WPB 4
 #endif
 constexpr int kWavesPerBlock = GCN_WPB;
-constexpr int kDefaultItemCost = 64;
-constexpr int kDefaultLongThresh = 256;
+constexpr int kDefaultItemCost = GCN_DEFAULT_ITEM_COST;
+constexpr int kDefaultLongThresh = GCN_DEFAULT_LONG_THRESH;
 
 thread_local char g_err[256] = "";
 

@@ -140,7 +140,8 @@ class CSRGraph:
         p = _native.GcnCsrPlan()
         p.n_rows, p.n_cols, p.nnz = n_rows, self.shape[1], self.nnz
         p.rowptr, p.rowptr_is64 = self.rowptr.data_ptr(), is64
-        p.long_thresh = self.long_thresh if self.long_thresh > 0 else 256
+        p.long_thresh = self.long_thresh if self.long_thresh > 0 else \
+            _native.GCN_DEFAULT_LONG_THRESH
         p.col, p.val = self.col.data_ptr(), self.val.data_ptr()
         p.n_items, p.items = ni, keep["items"].data_ptr()
         p.n_chunks, p.chunk_row, p.chunk_e0 = nc, keep["chunk_row"].data_ptr(), \

@@ -22,6 +22,9 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert getattr(L, sym) is not None
     assert L.gcn_abi_version() == _native.GCN_ABI_VERSION
+    for name in ("GCN_ABI_VERSION", "GCN_DEFAULT_ITEM_COST", "GCN_DEFAULT_LONG_THRESH",
+                 "GCN_DTYPE_F32", "GCN_DTYPE_BF16"):
+        assert int(re.search(rf"#define {name}\s+(\d+)", hdr).group(1)) == getattr(_native, name)
 
 
 def test_plan_struct_layout_matches_header():
@@ -59,8 +62,9 @@ def test_planner_covers_every_row_exactly_once(dtype, seed):
     deg[rng.integers(0, n, size=20)] = rng.integers(257, 3000, size=20)   # long rows
     deg[rng.integers(0, n, size=200)] = 0                                  # empty rows
     rp = np.concatenate([[0], np.cumsum(deg)]).astype(dtype)
-    items, crow, ce0, lrow, lc0 = _plan(rp)
-    L = 256
+    L = (256, 0, 1000)[seed]                  # explicit, library default, explicit
+    items, crow, ce0, lrow, lc0 = _plan(rp, long_thresh=L)
+    L = L or _native.GCN_DEFAULT_LONG_THRESH
     covered = np.zeros(n, np.int32)
     for ra, rb in items:
         assert 0 < rb - ra <= 64

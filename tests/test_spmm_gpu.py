@@ -163,15 +163,16 @@ def test_spmm_matches_oracle_all_widths(oracle, dev, F):
     from pygcn_amd import spmm_csr
     a = _skewed_csr(oracle, 3000, 2500, 6, seed=F, empties=300,
                     hubs=((5, 255), (6, 256), (7, 257), (100, 5000), (2999, 1025), (0, 700)))
-    g = _graph(a, dev)
     B = gin.dense((2500, F), 1000 + F)
-    out = spmm_csr(g, torch.from_numpy(B).to(dev))
-    assert_normwise(out.cpu(), a.matmul(B), TOL, f"A@B F={F}")
     G = gin.dense((3000, F), 2000 + F)
-    out_t = spmm_csr(g.t(), torch.from_numpy(G).to(dev))
-    assert_normwise(out_t.cpu(), a.t_matmul(G), TOL, f"A^T@G F={F}")
-    stats = g.schedule_stats()
-    assert stats["n_long"] == 4 and stats["n_chunks"] == 2 + 20 + 5 + 3
+    for lt, n_long, n_chunks in ((256, 4, 2 + 20 + 5 + 3), (0, 2, 5 + 2)):   # 0 = default (1024)
+        g = _graph(a, dev, long_thresh=lt)
+        out = spmm_csr(g, torch.from_numpy(B).to(dev))
+        assert_normwise(out.cpu(), a.matmul(B), TOL, f"A@B F={F} L={lt}")
+        out_t = spmm_csr(g.t(), torch.from_numpy(G).to(dev))
+        assert_normwise(out_t.cpu(), a.t_matmul(G), TOL, f"A^T@G F={F} L={lt}")
+        stats = g.schedule_stats()
+        assert stats["n_long"] == n_long and stats["n_chunks"] == n_chunks
 
 
 def test_spmm_int64_rowptr_and_strided_operands(oracle, dev):
