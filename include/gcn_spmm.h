@@ -39,7 +39,7 @@ extern "C" {
 #define GCN_ABI_VERSION 3
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
-#define GCN_DEFAULT_LONG_THRESH 1024   /* rows with more stored entries are chunked             */
+#define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
 
 /*
  * A CSR adjacency (or its transpose) plus the static launch schedule built for it once.

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
 GCN_ABI_VERSION = 3
 GCN_DEFAULT_ITEM_COST = 64
-GCN_DEFAULT_LONG_THRESH = 1024
+GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
 GCN_DTYPE_BF16 = 1
 

@@ -165,7 +165,7 @@ def test_spmm_matches_oracle_all_widths(oracle, dev, F):
                     hubs=((5, 255), (6, 256), (7, 257), (100, 5000), (2999, 1025), (0, 700)))
     B = gin.dense((2500, F), 1000 + F)
     G = gin.dense((3000, F), 2000 + F)
-    for lt, n_long, n_chunks in ((256, 4, 2 + 20 + 5 + 3), (0, 2, 5 + 2)):   # 0 = default (1024)
+    for lt, n_long, n_chunks in ((0, 4, 2 + 20 + 5 + 3), (1024, 2, 5 + 2)):   # 0 = default (256)
         g = _graph(a, dev, long_thresh=lt)
         out = spmm_csr(g, torch.from_numpy(B).to(dev))
         assert_normwise(out.cpu(), a.matmul(B), TOL, f"A@B F={F} L={lt}")
