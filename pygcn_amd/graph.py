@@ -31,7 +31,10 @@ def _require_cuda(t, what):
 class CSRGraph:
     """Sparse matrix A [n_rows, n_cols] in CSR on a HIP device, with its launch schedule."""
 
-    def __init__(self, rowptr, col, val, shape, item_cost=0, long_thresh=0):
+    def __init__(self, rowptr, col, val, shape, item_cost=0, long_thresh=0, validate=True):
+        """`validate` (default on; one-off, a few device reductions) checks what the kernels
+        assume — monotone row pointers ending at nnz and 0 <= col < n_cols — because an
+        out-of-range index would be an out-of-bounds gather on the GPU."""
         for name, t in (("rowptr", rowptr), ("col", col), ("val", val)):
             _require_cuda(t, name)
         n_rows, n_cols = int(shape[0]), int(shape[1])
@@ -39,6 +42,16 @@ class CSRGraph:
             raise RuntimeError("rowptr must be int32/int64 with n_rows+1 entries")
         if col.dtype != torch.int32 or val.dtype != torch.float32 or col.numel() != val.numel():
             raise RuntimeError("col must be int32 and val float32, same length")
+        if validate:
+            nnz = int(col.numel())
+            ok = int(rowptr[0]) == 0 and int(rowptr[-1]) == nnz
+            if ok and n_rows > 0:
+                ok = bool((rowptr[1:] >= rowptr[:-1]).all())
+            if ok and nnz > 0:
+                ok = int(col.min()) >= 0 and int(col.max()) < n_cols
+            if not ok:
+                raise RuntimeError("invalid CSR: rowptr must rise from 0 to nnz and every column "
+                                   f"index must lie in [0, {n_cols})")
         self.rowptr = rowptr.contiguous()
         self.col = col.contiguous()
         self.val = val.contiguous()
@@ -180,7 +193,7 @@ class CSRGraph:
             _native.check(rc, "gcn_csr_transpose_device")
             del ws
             g = CSRGraph(rowptr_t, col_t, val_t, (n_cols, n_rows), item_cost=self.item_cost,
-                         long_thresh=self.long_thresh)
+                         long_thresh=self.long_thresh, validate=False)
             g._t = self
             self._t = g
         return self._t

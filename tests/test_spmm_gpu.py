@@ -286,6 +286,13 @@ def test_errors_are_runtime_errors(dev):
     with pytest.raises(RuntimeError, match="HIP device"):
         spmm_csr(g, torch.ones(2, 4))
     assert spmm_csr(g, torch.ones(2, 0, device=dev)).shape == (2, 0)
+    # malformed CSR is rejected at construction (an out-of-range column would be an OOB gather)
+    i32 = dict(dtype=torch.int32, device=dev)
+    for rp, c in (([0, 1, 2], [0, 2]), ([0, 2, 1], [0, 1]), ([0, 1, 3], [0, 1]), ([1, 1, 2], [0, 1]),
+                  ([0, 1, 2], [-1, 1])):
+        with pytest.raises(RuntimeError, match="invalid CSR"):
+            CSRGraph(torch.tensor(rp, **i32), torch.tensor(c, **i32), torch.ones(2, device=dev),
+                     (2, 2))
 
 
 def test_batched_samples_match_per_sample_loop(oracle, dev):
