@@ -12,7 +12,8 @@ on the device and are resident in HBM before the timed region starts.
 Printed JSON (rank 0, one line):
   value        = fwd SpMM throughput, nnz(A_hat) / mean duration of the forward `gcn_spmm_csr`
                  launches inside the timed region, in GEdge/s (all ranks' edges / slowest rank at
-                 N > 1, where the launch window includes the all-gather it depends on)
+                 N > 1, where the window includes the exchange step — halo P2P or all-gather — the
+                 product depends on)
   ms_per_step  = fwd+bwd ms/epoch (wall, max over ranks)
   roofline     = algorithmic bytes of one forward SpMM launch / its mean duration vs 8 TB/s HBM
   cpu_baseline = the oracle's OpenMP CSR SpMM (a CPU port of the reference's call,

@@ -367,8 +367,8 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // masked-off entries re-read row 0 with weight 0 only if row 0 is finite; avoid the
-            // multiply instead: load from the entry's own clamp (col 0) but zero the raw value.
+            // entries past the end of the row point at row 0 (a harmless cached read); their
+            // products are skipped below, so non-finite values there cannot leak in
             x[u] = *(const Raw *)((const char *)p.B + (int64_t)c[u] * ldb_bytes + ld_off);
         }
 #pragma unroll
