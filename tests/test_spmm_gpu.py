@@ -536,3 +536,20 @@ def test_native_row_normalize_matches_reference_semantics(dev):
     np.testing.assert_allclose(got.toarray(), ref.toarray(), rtol=2e-6, atol=0)
     assert not np.isnan(g.val.cpu().numpy()).any()
     np.testing.assert_array_equal(got.toarray()[[7, 20]], 0.0)
+
+
+def test_c_abi_from_plain_cpp_without_torch(dev, tmp_path):
+    """The boundary is a C-ABI: a stand-alone C++ program (hipMalloc + the entry points of
+    include/gcn_spmm.h, no PyTorch) runs forward, device transpose and backward and checks them."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.join(ROOT, "pygcn_amd", "csrc")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "c_abi_smoke.cpp"), "-L", libdir,
+                           "-lgcn_spmm", f"-Wl,-rpath,{libdir}", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "C_ABI_SMOKE OK" in out.stdout, out.stdout + out.stderr
