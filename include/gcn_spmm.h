@@ -185,6 +185,17 @@ int gcn_csr_transpose_device(const void *rowptr, int rowptr_is64, const int32_t 
 int gcn_row_normalize_device(const void *rowptr, int rowptr_is64, float *val, int64_t n_rows,
                              void *stream);
 
+/*
+ * Y[M, 256] = X[M, 256] · W[256, 256] — the dense half of the layer, `torch.mm(input, weight)`
+ * (pygcn/layers.py:33) and the grad_input GEMM of its backward, for the hidden width 256 of
+ * configs C3/C4.  fp32 in / out / accumulate; operands are split into three bf16 parts on the
+ * fly and multiplied with six bf16 MFMAs (fp32-level accuracy, see gcn_gemm.hip).  DEVICE
+ * pointers; X rows 16-byte aligned; workspace >= gcn_gemm_xw256_workspace_bytes() (384 KiB).
+ */
+size_t gcn_gemm_xw256_workspace_bytes(void);
+int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
+                       int64_t M, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

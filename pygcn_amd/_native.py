@@ -45,7 +45,7 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_spmm_csr_ep",
            "gcn_relu_dropout_backward", "gcn_csr_transpose_host",
            "gcn_csr_transpose_workspace_bytes", "gcn_csr_transpose_device",
-           "gcn_row_normalize_device")
+           "gcn_row_normalize_device", "gcn_gemm_xw256_workspace_bytes", "gcn_gemm_xw256_f32")
 
 _lib = None
 
@@ -108,6 +108,12 @@ def lib():
     L.gcn_row_normalize_device.restype = ctypes.c_int
     L.gcn_row_normalize_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int64, ctypes.c_void_p]
+    L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_gemm_xw256_workspace_bytes.argtypes = []
+    L.gcn_gemm_xw256_f32.restype = ctypes.c_int
+    L.gcn_gemm_xw256_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                     ctypes.c_size_t, ctypes.c_void_p]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

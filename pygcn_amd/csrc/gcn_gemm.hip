@@ -1,0 +1,236 @@
+// gcn_gemm.hip — Y[M,256] = X[M,256] · W[256,256] for the dense half of GraphConvolution
+// (reference pygcn/layers.py:33 `support = torch.mm(input, self.weight)` and the grad_input GEMM
+// of its backward), written for gfx950 MFMA.  SURVEY §8 row f2.
+//
+// fp32 in, fp32 out, fp32 accumulate.  gfx950 has no reduced-precision fp32 MFMA (no xf32), and
+// the exact fp32 MFMA runs at 1/16 of the bf16 rate, so each fp32 operand is split on the fly into
+// three bf16 parts x = h + m + l (8 + 8 + 8 significant bits = the 24 of fp32) and the product is
+// formed from the six partial products that matter:
+//     x·w ≈ h·h' + h·m' + m·h' + h·l' + l·h' + m·m'        (dropped terms <= 2^-24 relative)
+// = 6 bf16 MFMAs instead of 16 bf16-equivalents of one fp32 MFMA, with fp32-level accuracy
+// (checked against an fp64 product in tests/test_gemm_gpu.py).
+//
+// Structure: a 512-thread workgroup owns 256 rows; each of its 8 waves owns 32 rows x all 256
+// columns (8 accumulator tiles of 32x32 = 128 VGPRs, held TRANSPOSED so a lane owns an output row
+// and stores 16 bytes at a time).  Per 16-deep K step (the K loop is fully unrolled) a wave loads
+// its X fragment straight from global memory in MFMA layout (8 consecutive floats per lane, two
+// steps ahead), splits it, and multiplies with the pre-split W chunk (3 x 8 KiB, fragment-ordered)
+// that the workgroup staged in LDS (double-buffered, one barrier per K step).  W is split and
+// fragment-ordered once per call by a small prep kernel into a 384 KiB workspace.
+//
+// Measured on MI355X at M = 10^7 (tools/gemm_custom_probe.py): 8.0 ms against 9.95 ms for
+// hipBLASLt's fp32 MFMA kernel; error against an fp64 product 6e-7 normwise (hipBLASLt fp32:
+// 7e-7).  Ablations: the MFMA + LDS-read core alone runs 5.1 ms (the chip lowers its clock in
+// MFMA-dense loops), stores +0.7 ms, W staging + barrier +1.1 ms, the fragment-shaped X loads
+// +1.3 ms (TA-inefficient; full-line staging through LDS is the next step).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gcn_spmm.h"
+
+int gcn_internal_fail(int code, const char *msg);
+int gcn_internal_fail_hip(int hip_error, const char *where);
+
+namespace {
+
+constexpr int kN = 256, kK = 256;
+constexpr int kChunk = 16;                         // K per MFMA 32x32x16
+constexpr int kChunks = kK / kChunk;               // 16
+constexpr int kFragBytes = 64 * 16;                // one B fragment: 64 lanes x 8 bf16
+constexpr int kChunkBytes = 3 * 8 * kFragBytes;    // 3 splits x 8 column blocks = 24 KiB
+#ifndef GEMM_WAVES
+#define GEMM_WAVES 8
+#endif
+constexpr int kWaves = GEMM_WAVES;                 // waves per workgroup, 32 rows each
+constexpr int kThreads = 64 * kWaves;
+constexpr int kTileRows = 32 * kWaves;
+constexpr int kWLoads = kChunkBytes / 16 / kThreads;   // 16-byte pieces of a W chunk per thread
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_round(float x)   // value of x rounded to bf16, as a float
+{
+    f32x2 v = {x, 0.f};
+    bf16x2 b = __builtin_convertvector(v, bf16x2);
+    const uint32_t bits = __builtin_bit_cast(uint32_t, b) << 16;
+    return __uint_as_float(bits);
+}
+
+// x -> (h, m, l) as raw bf16 bit patterns
+__device__ __forceinline__ void split3(float x, uint16_t &h, uint16_t &m, uint16_t &l)
+{
+    const float fh = bf16_round(x);
+    const float r1 = x - fh;
+    const float fm = bf16_round(r1);
+    const float fl = bf16_round(r1 - fm);
+    h = (uint16_t)(__float_as_uint(fh) >> 16);
+    m = (uint16_t)(__float_as_uint(fm) >> 16);
+    l = (uint16_t)(__float_as_uint(fl) >> 16);
+}
+
+// W [K=256][N=256] fp32 row-major -> workspace [chunk 16][split 3][colblock 8][lane 64][8 bf16],
+// element j of lane l of fragment (chunk, colblock): k = 16*chunk + 8*(l>>5) + j, n = 32*cb + (l&31)
+__global__ __launch_bounds__(256) void split_w_kernel(const float *__restrict__ W, int64_t ldw,
+                                                      uint16_t *__restrict__ wsp)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one (chunk, cb, lane) per thread
+    if (idx >= kChunks * 8 * 64) return;
+    const int lane = idx & 63, cb = (idx >> 6) & 7, chunk = idx >> 9;
+    const int n = 32 * cb + (lane & 31);
+    const int k0 = kChunk * chunk + 8 * (lane >> 5);
+    uint16_t h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(W[(int64_t)(k0 + j) * ldw + n], h[j], m[j], l[j]);
+    uint16_t *base = wsp + (size_t)chunk * (kChunkBytes / 2);
+    uint16_t *dh = base + ((0 * 8 + cb) * 64 + lane) * 8;
+    uint16_t *dm = base + ((1 * 8 + cb) * 64 + lane) * 8;
+    uint16_t *dl = base + ((2 * 8 + cb) * 64 + lane) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dh[j] = h[j];
+        dm[j] = m[j];
+        dl[j] = l[j];
+    }
+}
+
+__device__ __forceinline__ u32x4 pack8(const uint16_t (&v)[8])
+{
+    u32x4 r = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+               (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16)};
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__restrict__ X, int64_t ldx,
+                                                            const uint16_t *__restrict__ wsp,
+                                                            float *__restrict__ Y, int64_t ldy,
+                                                            int64_t M)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = (int64_t)blockIdx.x * kTileRows + 32 * wave + (lane & 31);
+    const bool row_ok = row < M;
+    const float *xrow = X + (row_ok ? row : 0) * ldx + 8 * (lane >> 5);
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+    // stage W chunk c into LDS buffer b: 24 KiB = 256 threads x 6 x 16 B, linear copy
+    u32x4 wreg[kWLoads];
+    auto w_load = [&](int c) {
+        const u32x4 *src = (const u32x4 *)((const unsigned char *)wsp + (size_t)c * kChunkBytes);
+#pragma unroll
+        for (int i = 0; i < kWLoads; ++i) wreg[i] = src[i * kThreads + tid];
+    };
+    auto w_store = [&](int b) {
+        u32x4 *dst = (u32x4 *)(lds + b * kChunkBytes);
+#pragma unroll
+        for (int i = 0; i < kWLoads; ++i) dst[i * kThreads + tid] = wreg[i];
+    };
+    // A fragments: a statically indexed ring of 3 steps (this step + two steps of prefetch); the
+    // K loop is fully unrolled so that ring slots are compile-time registers and no copies (which
+    // would force the prefetched loads to complete) are needed
+    f32x4 ar[3][2];
+    auto a_fetch = [&](int c, f32x4 &lo, f32x4 &hi) {
+        const f32x4 *p = (const f32x4 *)(xrow + c * kChunk);
+        lo = p[0];
+        hi = p[1];
+    };
+
+    w_load(0);
+    a_fetch(0, ar[0][0], ar[0][1]);
+    a_fetch(1, ar[1][0], ar[1][1]);
+    w_store(0);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        __syncthreads();   // chunk c is in lds[c & 1]; everyone is done with lds[(c + 1) & 1]
+        // split this step's A fragment (row_ok == false rows contribute zeros)
+        const f32x4 a0 = ar[c % 3][0], a1 = ar[c % 3][1];
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        uint16_t h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(row_ok ? av[j] : 0.f, h[j], m[j], l[j]);
+        const u32x4 Ah = pack8(h), Am = pack8(m), Al = pack8(l);
+        if (c + 1 < kChunks) w_load(c + 1);   // prefetch: W one step ahead, A two steps ahead
+        if (c + 2 < kChunks) a_fetch(c + 2, ar[(c + 2) % 3][0], ar[(c + 2) % 3][1]);
+        const unsigned char *buf = lds + (c & 1) * kChunkBytes;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const u32x4 Bh = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
+            const u32x4 Bm = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
+            const u32x4 Bl = *(const u32x4 *)(buf + ((2 * 8 + nb) * 64 + lane) * 16);
+            // W fragment as the MFMA "A" operand, X fragment as "B": the accumulator then holds
+            // the TRANSPOSED 32x32 tile (lane = output row, 4 consecutive registers = 4
+            // consecutive output columns), which stores as 16 bytes per lane
+            f32x16 t = acc[nb];
+            t = mfma(Bh, Al, t);     // smallest terms first
+            t = mfma(Bl, Ah, t);
+            t = mfma(Bm, Am, t);
+            t = mfma(Bh, Am, t);
+            t = mfma(Bm, Ah, t);
+            t = mfma(Bh, Ah, t);
+            acc[nb] = t;
+        }
+        if (c + 1 < kChunks) w_store((c + 1) & 1);
+    }
+
+    // transposed C/D layout: output row = lane & 31, output column = 32*nb + 8*(reg >> 2) +
+    // 4*(lane >> 5) + (reg & 3)
+    if (row_ok) {
+        float *yrow = Y + row * ldy + 4 * (lane >> 5);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+                *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
+            }
+        }
+    }
+}
+
+}   // namespace
+
+extern "C" {
+
+size_t gcn_gemm_xw256_workspace_bytes(void) { return (size_t)kChunks * kChunkBytes; }
+
+int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
+                       int64_t M, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32: bad sizes");
+    if (M == 0) return 0;
+    if (X == nullptr || W == nullptr || Y == nullptr || workspace == nullptr)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32: NULL pointer");
+    if (workspace_bytes < gcn_gemm_xw256_workspace_bytes())
+        return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw256_f32: workspace too small");
+    if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 4) != 0 ||
+        (ldy % 4) != 0)
+        return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32: X / Y rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(split_w_kernel, dim3(kChunks * 8 * 64 / 256), dim3(256), 0, s, W, ldw,
+                       (uint16_t *)workspace);
+    const int64_t tiles = (M + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(gemm_xw256_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
+                       (const uint16_t *)workspace, Y, ldy, M);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32 launch");
+    return 0;
+}
+
+}   // extern "C"

@@ -131,6 +131,26 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
+def gemm_xw256(X, W):
+    """X[M,256] · W[256,256] through the hand-written split-bf16 MFMA kernel
+    (C-ABI gcn_gemm_xw256_f32; fp32 in/out, fp32-level accuracy).  None if the operands do not fit
+    the kernel's fixed shape / alignment (the caller then uses torch.mm — hipBLASLt)."""
+    if (X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda or X.dim() != 2
+            or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
+            or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
+        return None
+    L = _native.lib()
+    Y = torch.empty((X.shape[0], 256), dtype=torch.float32, device=X.device)
+    ws_bytes = L.gcn_gemm_xw256_workspace_bytes()
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    with torch.cuda.device(X.device):
+        rc = L.gcn_gemm_xw256_f32(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), Y.data_ptr(),
+                                  Y.stride(0), X.shape[0], ws.data_ptr(), ws_bytes,
+                                  torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_gemm_xw256_f32")
+    return Y
+
+
 class DenseMMFunction(torch.autograd.Function):
     """`torch.mm(input, weight)` (reference pygcn/layers.py:33) with a K-split weight gradient.
 
@@ -138,7 +158,10 @@ class DenseMMFunction(torch.autograd.Function):
     vertices (10⁷ at config C4).  hipBLASLt answers that shape with a stream-K kernel at 21.5 ms;
     cutting N into 128 slabs, one batched GEMM over the slabs and a sum of the 128 small partial
     products takes 8.7 ms on MI355X (tools/gemm_probe.py) and is at least as accurate (shorter
-    fp32 accumulation chains)."""
+    fp32 accumulation chains).
+
+    Forward and grad_input use the hand-written MFMA kernel when the layer is 256 -> 256 fp32
+    (gemm_xw256: 8.0 ms vs hipBLASLt 9.95 ms at N = 10⁷), torch.mm otherwise."""
 
     K_SPLIT = 128
     MIN_ROWS = 1 << 17
@@ -146,14 +169,17 @@ class DenseMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight):
         ctx.save_for_backward(input, weight)
-        return torch.mm(input, weight)
+        out = gemm_xw256(input, weight)
+        return out if out is not None else torch.mm(input, weight)
 
     @staticmethod
     def backward(ctx, grad):
         input, weight = ctx.saved_tensors
         grad_in = grad_w = None
         if ctx.needs_input_grad[0]:
-            grad_in = torch.mm(grad, weight.t())
+            grad_in = gemm_xw256(grad, weight.t().contiguous())
+            if grad_in is None:
+                grad_in = torch.mm(grad, weight.t())
         if ctx.needs_input_grad[1]:
             n, b = input.shape[0], DenseMMFunction.K_SPLIT
             if n >= DenseMMFunction.MIN_ROWS and input.is_contiguous() and grad.is_contiguous():
