@@ -21,8 +21,12 @@
 // Measured on MI355X at M = 10^7 (tools/gemm_custom_probe.py): 8.0 ms against 9.95 ms for
 // hipBLASLt's fp32 MFMA kernel; error against an fp64 product 6e-7 normwise (hipBLASLt fp32:
 // 7e-7).  Ablations: the MFMA + LDS-read core alone runs 5.1 ms (the chip lowers its clock in
-// MFMA-dense loops), stores +0.7 ms, W staging + barrier +1.1 ms, the fragment-shaped X loads
-// +1.3 ms (TA-inefficient; full-line staging through LDS is the next step).
+// MFMA-dense loops: 1.91 GHz), stores +0.7 ms, W staging + barrier +1.1 ms, the X loads +1.3 ms.
+// Counters (profiles/r01_gemm_pmc.md): the MFMA pipe is busy 49 % of the kernel; waves spend 53 %
+// of their cycles stalled on issue and 34 % in s_waitcnt / s_barrier.  Tried without gain: X
+// staged through wave-private LDS in full 128-B lines (7.9 ms), 4-wave workgroups (8.3 ms), a
+// deeper X prefetch ring; s_setprio around the MFMA run is worth 4 %.  Next step would be the
+// guide's multi-phase schedule (counted vmcnt, LDS-DMA for the W stream, staggered wave halves).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -177,12 +181,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
             // the TRANSPOSED 32x32 tile (lane = output row, 4 consecutive registers = 4
             // consecutive output columns), which stores as 16 bytes per lane
             f32x16 t = acc[nb];
+            __builtin_amdgcn_s_setprio(1);   // keep the partner wave's VALU/loads out of the MFMA run
             t = mfma(Bh, Al, t);     // smallest terms first
             t = mfma(Bl, Ah, t);
             t = mfma(Bm, Am, t);
             t = mfma(Bh, Am, t);
             t = mfma(Bm, Ah, t);
             t = mfma(Bh, Ah, t);
+            __builtin_amdgcn_s_setprio(0);
             acc[nb] = t;
         }
         if (c + 1 < kChunks) w_store((c + 1) & 1);
