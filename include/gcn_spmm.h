@@ -154,6 +154,19 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
                               int64_t n_elems, float scale, void *stream);
 
 /*
+ * The same backward pass for fp32 [n_rows, F] row-major tensors, producing in the same sweep the
+ * column sums of its result: colsum[f] = sum_rows grad_pre[row, f] — the bias gradient of
+ * `output + self.bias` (pygcn/layers.py:35-36).  `out == NULL` skips the masking (plain column
+ * sums of grad_out; grad_pre is then ignored).  Deterministic (per-block partial rows added in
+ * block order, no float atomics).  F must be a multiple of 4 with F/4 dividing 256
+ * (4, 8, ..., 256, 512, 1024); scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F).
+ */
+size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F);
+int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
+                                     float *colsum, int64_t n_rows, int64_t F, float scale,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of
  * A^T lists its entries in increasing source-row order (deterministic backward sums).
  * rowptr_t[n_cols+1] has the width of rowptr; col_t[nnz]; val_t[nnz].

@@ -45,7 +45,8 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_spmm_workspace_bytes", "gcn_spmm_csr", "gcn_spmm_csr_ep",
            "gcn_relu_dropout_backward", "gcn_csr_transpose_host",
            "gcn_csr_transpose_workspace_bytes", "gcn_csr_transpose_device",
-           "gcn_row_normalize_device", "gcn_gemm_xw256_workspace_bytes", "gcn_gemm_xw256_f32")
+           "gcn_row_normalize_device", "gcn_gemm_xw256_workspace_bytes", "gcn_gemm_xw256_f32",
+           "gcn_bwd_colsum_workspace_bytes", "gcn_relu_dropout_backward_colsum")
 
 _lib = None
 
@@ -108,6 +109,13 @@ def lib():
     L.gcn_row_normalize_device.restype = ctypes.c_int
     L.gcn_row_normalize_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int64, ctypes.c_void_p]
+    L.gcn_bwd_colsum_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_bwd_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.gcn_relu_dropout_backward_colsum.restype = ctypes.c_int
+    L.gcn_relu_dropout_backward_colsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                                   ctypes.c_void_p]
     L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_workspace_bytes.argtypes = []
     L.gcn_gemm_xw256_f32.restype = ctypes.c_int

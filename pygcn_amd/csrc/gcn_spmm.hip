@@ -594,6 +594,59 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// the same pass with the column sums of its result (grad_bias = sum over rows of grad_pre,
+// autograd of `output + self.bias`, pygcn/layers.py:35-36) produced on the fly.  A 256-thread
+// block owns a contiguous slab of rows; thread t owns the 4 columns 4*(t % CG) (CG = F/4 column
+// groups) of every (256/CG)-th row, keeps 4 running sums, and the block writes one partial row
+// [F]; a second tiny kernel adds the partial rows in block order (deterministic, no atomics).
+// MASK = false gives a plain column sum (layer without a fused ReLU).
+// ------------------------------------------------------------------------------------------
+template <bool MASK>
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict__ grad_out,
+                                                         const float *__restrict__ out,
+                                                         float *__restrict__ grad_pre,
+                                                         float *__restrict__ partial, int64_t n_rows,
+                                                         int F, float scale, int rows_per_block)
+{
+    __shared__ float red[256 * 4];
+    const int CG = F >> 2, RL = 256 / CG;         // column groups, row lanes
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + (int64_t)rows_per_block, n_rows);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+        const int64_t off = r * F + 4 * cg;
+        f32x4 g = *(const f32x4 *)(grad_out + off);
+        if (MASK) {
+            const f32x4 o = *(const f32x4 *)(out + off);
+            g.x = o.x > 0.f ? g.x * scale : 0.f;
+            g.y = o.y > 0.f ? g.y * scale : 0.f;
+            g.z = o.z > 0.f ? g.z * scale : 0.f;
+            g.w = o.w > 0.f ? g.w * scale : 0.f;
+            *(f32x4 *)(grad_pre + off) = g;
+        }
+        acc += g;
+    }
+    *(f32x4 *)(red + threadIdx.x * 4) = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < RL; ++k) acc += *(const f32x4 *)(red + (k * CG + cg) * 4);   // fixed order
+        *(f32x4 *)(partial + (int64_t)blockIdx.x * F + 4 * cg) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ partial,
+                                                            float *__restrict__ colsum, int n_blocks,
+                                                            int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * F + f];
+    colsum[f] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int LPR>
@@ -910,6 +963,53 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "relu_dropout_backward launch");
+    return 0;
+}
+
+static bool colsum_shape_ok(int64_t F)
+{
+    return F >= 4 && F <= 1024 && (F % 4) == 0 && (256 % (F / 4)) == 0;
+}
+
+size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F)
+{
+    if (n_rows <= 0 || !colsum_shape_ok(F)) return 0;
+    const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
+    return (size_t)blocks * (size_t)F * sizeof(float);
+}
+
+int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
+                                     float *colsum, int64_t n_rows, int64_t F, float scale,
+                                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n_rows < 0 || !colsum_shape_ok(F))
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of 4 with "
+                                  "F/4 dividing 256");
+    if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows == 0) {
+        hipError_t e = hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), s);
+        return e == hipSuccess ? 0 : fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
+    }
+    const size_t need = gcn_bwd_colsum_workspace_bytes(n_rows, F);
+    if (workspace == nullptr || workspace_bytes < need)
+        return fail(GCN_E_WORKSPACE, "gcn_relu_dropout_backward_colsum: workspace too small");
+    if (((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)grad_pre | (uintptr_t)workspace) % 16 != 0)
+        return fail(GCN_E_ALIGN, "gcn_relu_dropout_backward_colsum: 16-byte alignment required");
+    const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
+    const int rows_per_block = (int)((n_rows + blocks - 1) / blocks);
+    if (out != nullptr)
+        hipLaunchKernelGGL(bwd_colsum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
+                           out, grad_pre, (float *)workspace, n_rows, (int)F, scale, rows_per_block);
+    else
+        hipLaunchKernelGGL(bwd_colsum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
+                           (const float *)nullptr, (float *)nullptr, (float *)workspace, n_rows, (int)F,
+                           scale, rows_per_block);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s,
+                       (const float *)workspace, colsum, (int)blocks, (int)F);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum launch");
     return 0;
 }
 

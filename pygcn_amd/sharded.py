@@ -32,7 +32,7 @@ import torch
 import torch.distributed as dist
 
 from .graph import CSRGraph
-from .spmm import relu_dropout_backward, spmm_csr
+from .spmm import _grad_pre_and_bias, spmm_csr
 
 
 def partition_rows(rowptr, world):
@@ -258,17 +258,13 @@ class ShardedSpMMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grad_support = grad_bias = None
-        if ctx.relu:
-            (out,) = ctx.saved_tensors
-            if grad_out.is_cuda:
-                grad_out = relu_dropout_backward(grad_out, out, ctx.scale)
-            else:   # gloo/CPU logic tests only (tests/ supply the CPU local product)
-                grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0) * ctx.scale
+        grad_support = None
+        out = ctx.saved_tensors[0] if ctx.relu else None
+        # grad_bias is this rank's partial sum: summed over ranks by allreduce_grads
+        grad_out, grad_bias = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale,
+                                                 ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = grad_out.sum(0)          # partial: summed over ranks by allreduce_grads
         return None, grad_support, grad_bias, None, None, None
 
 

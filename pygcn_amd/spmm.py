@@ -91,6 +91,51 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
     return res
 
 
+def backward_with_colsum(grad_out, out=None, scale=1.0):
+    """(grad_pre, column sums of grad_pre) in ONE pass over fp32 [N, F] tensors
+    (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
+    Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
+    relu_dropout_backward + torch's sum)."""
+    L = _native.lib()
+    if (grad_out.dtype != torch.float32 or grad_out.dim() != 2 or not grad_out.is_cuda
+            or not grad_out.is_contiguous() or grad_out.shape[0] == 0
+            or L.gcn_bwd_colsum_workspace_bytes(grad_out.shape[0], grad_out.shape[1]) == 0
+            or (out is not None and (out.dtype != torch.float32 or not out.is_contiguous()
+                                     or out.shape != grad_out.shape))):
+        return None
+    n, F = grad_out.shape
+    grad_pre = torch.empty_like(grad_out) if out is not None else grad_out
+    colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
+    ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        rc = L.gcn_relu_dropout_backward_colsum(
+            grad_out.data_ptr(), out.data_ptr() if out is not None else None,
+            grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
+            ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_relu_dropout_backward_colsum")
+    return grad_pre, colsum
+
+
+def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):
+    """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask and
+    (optionally) produce the bias gradient, in one pass when the shape allows."""
+    grad_bias = None
+    if want_bias:
+        fused = backward_with_colsum(grad_out.contiguous(), out if relu else None, scale) \
+            if grad_out.is_cuda else None
+        if fused is not None:
+            return fused
+    if relu:
+        if grad_out.is_cuda:
+            grad_out = relu_dropout_backward(grad_out, out, scale)
+        else:   # gloo/CPU logic tests only (tests/ supply the CPU local product)
+            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0) * scale
+    if want_bias:
+        grad_bias = grad_out.sum(0)
+    return grad_out, grad_bias
+
+
 def next_dropout_seed():
     """64-bit seed drawn from torch's default CPU generator: reproducible under
     torch.manual_seed, no device synchronisation."""
@@ -120,14 +165,12 @@ class SpMMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grad_B = grad_bias = None
-        if ctx.relu:
-            (out,) = ctx.saved_tensors
-            grad_out = relu_dropout_backward(grad_out, out, ctx.scale)
+        grad_B = None
+        out = ctx.saved_tensors[0] if ctx.relu else None
+        grad_out, grad_bias = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale,
+                                                 ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            grad_bias = grad_out.sum(0)
         return None, grad_B, grad_bias, None, None, None
 
 
