@@ -155,22 +155,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
         hi = p[1];
     };
 
+    // split one prefetched X fragment into its three bf16 parts (rows past M contribute zeros)
+    u32x4 Ah, Am, Al;
+    auto split_frag = [&](const f32x4 &lo, const f32x4 &hi) {
+        const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint16_t h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(row_ok ? av[j] : 0.f, h[j], m[j], l[j]);
+        Ah = pack8(h);
+        Am = pack8(m);
+        Al = pack8(l);
+    };
+
     w_load(0);
     a_fetch(0, ar[0][0], ar[0][1]);
     a_fetch(1, ar[1][0], ar[1][1]);
     w_store(0);
+    split_frag(ar[0][0], ar[0][1]);
 #pragma unroll
     for (int c = 0; c < kChunks; ++c) {
         __syncthreads();   // chunk c is in lds[c & 1]; everyone is done with lds[(c + 1) & 1]
-        // split this step's A fragment (row_ok == false rows contribute zeros)
-        const f32x4 a0 = ar[c % 3][0], a1 = ar[c % 3][1];
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        uint16_t h[8], m[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(row_ok ? av[j] : 0.f, h[j], m[j], l[j]);
-        const u32x4 Ah = pack8(h), Am = pack8(m), Al = pack8(l);
-        if (c + 1 < kChunks) w_load(c + 1);   // prefetch: W one step ahead, A two steps ahead
+        if (c + 1 < kChunks) w_load(c + 1);   // prefetch: W one step ahead, X two steps ahead
         if (c + 2 < kChunks) a_fetch(c + 2, ar[(c + 2) % 3][0], ar[(c + 2) % 3][1]);
+        const u32x4 Xh = Ah, Xm = Am, Xl = Al;
         const unsigned char *buf = lds + (c & 1) * kChunkBytes;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
@@ -182,16 +189,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
             // consecutive output columns), which stores as 16 bytes per lane
             f32x16 t = acc[nb];
             __builtin_amdgcn_s_setprio(1);   // keep the partner wave's VALU/loads out of the MFMA run
-            t = mfma(Bh, Al, t);     // smallest terms first
-            t = mfma(Bl, Ah, t);
-            t = mfma(Bm, Am, t);
-            t = mfma(Bh, Am, t);
-            t = mfma(Bm, Ah, t);
-            t = mfma(Bh, Ah, t);
+            t = mfma(Bh, Xl, t);     // smallest terms first
+            t = mfma(Bl, Xh, t);
+            t = mfma(Bm, Xm, t);
+            t = mfma(Bh, Xm, t);
+            t = mfma(Bm, Xh, t);
+            t = mfma(Bh, Xh, t);
             __builtin_amdgcn_s_setprio(0);
             acc[nb] = t;
         }
-        if (c + 1 < kChunks) w_store((c + 1) & 1);
+        if (c + 1 < kChunks) {
+            w_store((c + 1) & 1);
+            // split the NEXT step's X fragment here, behind this step's MFMA run, so that it
+            // overlaps the partner wave's MFMAs instead of idling the pipe right after the barrier
+            split_frag(ar[(c + 1) % 3][0], ar[(c + 1) % 3][1]);
+        }
     }
 
     // transposed C/D layout: output row = lane & 31, output column = 32*nb + 8*(reg >> 2) +
