@@ -24,9 +24,10 @@ same layer (reference pygcn/layers.py:32-38):
     no remote rank at all (self-loop-only vertices), and xGMI is point-to-point, so sending only
     what is needed, directly owner -> consumer, is the right shape for it.
 
-The local product is `pygcn_amd.spmm.spmm_csr` (HIP).  `graph_factory` / `spmm_fn` exist so the
+The local product is `pygcn_amd.spmm.spmm_csr` (HIP) and the local backward pass
+`pygcn_amd.spmm._grad_pre_and_bias` (HIP).  `graph_factory` / `spmm_fn` / `bwd_fn` exist so the
 partition / exchange logic can be exercised on CPU with gloo in tests/, where tests/ (never this
-package) supplies the CPU oracle as the local product.
+package) supplies CPU stand-ins (the oracle) for them.
 """
 import torch
 import torch.distributed as dist
@@ -162,7 +163,7 @@ class ShardedGraph:
     padded all-gather layout.  Accepted as `adj` by GraphConvolution.forward."""
 
     def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
-                 graph_factory=CSRGraph, spmm_fn=spmm_csr, **plan_kw):
+                 graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias, **plan_kw):
         if exchange not in ("halo", "allgather"):
             raise RuntimeError("exchange must be 'halo' or 'allgather'")
         self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
@@ -172,6 +173,7 @@ class ShardedGraph:
         self.n_local = self.r1 - self.r0
         self.max_rows = max(bounds[i + 1] - bounds[i] for i in range(world))
         self._spmm = spmm_fn
+        self._bwd = bwd_fn
         self.nnz_local = int(a_block[1].numel())
         self.halo = self.halo_t = None
         blocks = []
@@ -261,8 +263,8 @@ class ShardedSpMMFunction(torch.autograd.Function):
         grad_support = None
         out = ctx.saved_tensors[0] if ctx.relu else None
         # grad_bias is this rank's partial sum: summed over ranks by allreduce_grads
-        grad_out, grad_bias = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale,
-                                                 ctx.has_bias and ctx.needs_input_grad[2])
+        grad_out, grad_bias = ctx.sg._bwd(grad_out, out, ctx.relu, ctx.scale,
+                                          ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
         return None, grad_support, grad_bias, None, None, None

@@ -96,8 +96,9 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
     (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
+    _require_cuda(grad_out, "grad_out")
     L = _native.lib()
-    if (grad_out.dtype != torch.float32 or grad_out.dim() != 2 or not grad_out.is_cuda
+    if (grad_out.dtype != torch.float32 or grad_out.dim() != 2
             or not grad_out.is_contiguous() or grad_out.shape[0] == 0
             or L.gcn_bwd_colsum_workspace_bytes(grad_out.shape[0], grad_out.shape[1]) == 0
             or (out is not None and (out.dtype != torch.float32 or not out.is_contiguous()
@@ -119,18 +120,14 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
 
 def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):
     """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask and
-    (optionally) produce the bias gradient, in one pass when the shape allows."""
+    (optionally) produce the bias gradient, in one HIP pass when the shape allows."""
     grad_bias = None
     if want_bias:
-        fused = backward_with_colsum(grad_out.contiguous(), out if relu else None, scale) \
-            if grad_out.is_cuda else None
+        fused = backward_with_colsum(grad_out.contiguous(), out if relu else None, scale)
         if fused is not None:
             return fused
     if relu:
-        if grad_out.is_cuda:
-            grad_out = relu_dropout_backward(grad_out, out, scale)
-        else:   # gloo/CPU logic tests only (tests/ supply the CPU local product)
-            grad_out = torch.ops.aten.threshold_backward(grad_out, out, 0) * scale
+        grad_out = relu_dropout_backward(grad_out, out, scale)
     if want_bias:
         grad_bias = grad_out.sum(0)
     return grad_out, grad_bias

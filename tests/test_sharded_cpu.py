@@ -44,6 +44,13 @@ def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd"):
     return torch.from_numpy(y)
 
 
+def _cpu_bwd(grad_out, out, relu, scale, want_bias):
+    """CPU stand-in for the HIP backward pass (mask through out > 0, bias gradient)."""
+    if relu:
+        grad_out = torch.where(out > 0, grad_out * scale, torch.zeros_like(grad_out))
+    return grad_out, (grad_out.sum(0) if want_bias else None)
+
+
 def _worker(rank, world, port, n, n_edges, out_dir, exchange):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -59,7 +66,8 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         fin, nhid, ncls = 24, 32, 16
         rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")   # same on every rank
         sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, exchange=exchange,
-                                          graph_factory=_CpuGraph, spmm_fn=_cpu_spmm)
+                                          graph_factory=_CpuGraph, spmm_fn=_cpu_spmm,
+                                          bwd_fn=_cpu_bwd)
         recv, full = sg.exchange_rows()
         assert recv <= full and (exchange == "allgather") == (recv == full and sg.halo is None)
         assert sg.bounds[0] == 0 and sg.bounds[-1] == n and sg.n_local == sg.r1 - sg.r0
