@@ -111,7 +111,7 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "allgather"),
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (8, "halo"), (2, "allgather"),
                                             (3, "allgather")])
 def test_sharded_gcn_matches_unsharded_oracle(world, exchange, tmp_path, oracle):
     import torch.multiprocessing as mp
