@@ -103,6 +103,17 @@ __global__ __launch_bounds__(256) void split_w_kernel(const float *__restrict__ 
     }
 }
 
+// two floats -> packed (h, m, l) bf16 pairs, low half = x0 (one v_cvt_pk_bf16_f32 per part)
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    f32x2 v = {x0, x1};
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    f32x2 r = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+    f32x2 q = {r.x - __uint_as_float(m << 16), r.y - __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(q, bf16x2));
+}
+
 __device__ __forceinline__ u32x4 pack8(const uint16_t (&v)[8])
 {
     u32x4 r = {(uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
@@ -159,12 +170,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
     u32x4 Ah, Am, Al;
     auto split_frag = [&](const f32x4 &lo, const f32x4 &hi) {
         const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        uint16_t h[8], m[8], l[8];
+        uint32_t h[4], m[4], l[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split3(row_ok ? av[j] : 0.f, h[j], m[j], l[j]);
-        Ah = pack8(h);
-        Am = pack8(m);
-        Al = pack8(l);
+        for (int j = 0; j < 4; ++j)
+            split3_pair(row_ok ? av[2 * j] : 0.f, row_ok ? av[2 * j + 1] : 0.f, h[j], m[j], l[j]);
+        Ah = u32x4{h[0], h[1], h[2], h[3]};
+        Am = u32x4{m[0], m[1], m[2], m[3]};
+        Al = u32x4{l[0], l[1], l[2], l[3]};
     };
 
     w_load(0);
