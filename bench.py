@@ -165,6 +165,8 @@ def _install_host_staging(dist):
 
 def main():
     args = parse()
+    if args.spmm_only and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--spmm-only is a single-GPU profiling aid")
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child)
         return
