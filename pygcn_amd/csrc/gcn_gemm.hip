@@ -12,21 +12,25 @@
 //
 // Structure: a 512-thread workgroup owns 256 rows; each of its 8 waves owns 32 rows x all 256
 // columns (8 accumulator tiles of 32x32 = 128 VGPRs, held TRANSPOSED so a lane owns an output row
-// and stores 16 bytes at a time).  Per 16-deep K step (the K loop is fully unrolled) a wave loads
-// its X fragment straight from global memory in MFMA layout (8 consecutive floats per lane, two
-// steps ahead), splits it, and multiplies with the pre-split W chunk (3 x 8 KiB, fragment-ordered)
-// that the workgroup staged in LDS (double-buffered, one barrier per K step).  W is split and
-// fragment-ordered once per call by a small prep kernel into a 384 KiB workspace.
+// and stores 16 bytes at a time).  The K loop (16 steps of 16) is fully unrolled.  Per step a wave
+// multiplies its pre-split X fragment with the pre-split W chunk (3 x 8 KiB, fragment-ordered,
+// conflict-free) that the workgroup staged in LDS: two steps of W per barrier, double-buffered;
+// W fragments of column block nb+1 are read while the MFMAs of block nb run (two register sets);
+// the X fragment comes straight from global memory in MFMA layout (8 consecutive floats per lane,
+// fetched two steps ahead) and is split BEHIND the previous step's MFMA run (pinned there by an
+// opaque asm, or hipcc sinks it back to just after the barrier, where it idles the pipe).  W is
+// split and fragment-ordered once per call by a small prep kernel into a 384 KiB workspace.
 //
-// Measured on MI355X at M = 10^7 (tools/gemm_custom_probe.py): 8.0 ms against 9.95 ms for
-// hipBLASLt's fp32 MFMA kernel; error against an fp64 product 6e-7 normwise (hipBLASLt fp32:
-// 7e-7).  Ablations: the MFMA + LDS-read core alone runs 5.1 ms (the chip lowers its clock in
-// MFMA-dense loops: 1.91 GHz), stores +0.7 ms, W staging + barrier +1.1 ms, the X loads +1.3 ms.
-// Counters (profiles/r01_gemm_pmc.md): the MFMA pipe is busy 49 % of the kernel; waves spend 53 %
-// of their cycles stalled on issue and 34 % in s_waitcnt / s_barrier.  Tried without gain: X
-// staged through wave-private LDS in full 128-B lines (7.9 ms), 4-wave workgroups (8.3 ms), a
-// deeper X prefetch ring; s_setprio around the MFMA run is worth 4 %.  Next step would be the
-// guide's multi-phase schedule (counted vmcnt, LDS-DMA for the W stream, staggered wave halves).
+// Measured on MI355X at M = 10^7 (tools/gemm_custom_probe.py, same box): 7.6 ms against 10.0 ms
+// for hipBLASLt's fp32 MFMA kernel (first version 8.0 ms); error against an fp64 product 6e-7
+// normwise (hipBLASLt fp32: 7e-7).  Ablations on the first version: the MFMA + LDS-read core alone
+// 5.1 ms (the chip lowers its clock in MFMA-dense loops: 1.91 GHz), stores +0.7 ms, W staging +
+// barrier +1.1 ms, X loads +1.3 ms.  Counters (profiles/r01_gemm_pmc.md): MFMA pipe busy 49 %.
+// Steps that paid: s_setprio around the MFMA run (4 %), split behind the MFMA run + B-fragment
+// double buffering (4 %), two steps per barrier (2 %).  Tried without gain: X staged through
+// wave-private LDS in full 128-B lines, 4-wave workgroups, a deeper X ring, persistent workgroups
+// with cross-tile prefetch (spills at 256 VGPRs).  Next would be the guide's multi-phase schedule
+// (LDS-DMA for the W stream, staggered wave halves).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -49,7 +53,12 @@ constexpr int kChunkBytes = 3 * 8 * kFragBytes;    // 3 splits x 8 column blocks
 constexpr int kWaves = GEMM_WAVES;                 // waves per workgroup, 32 rows each
 constexpr int kThreads = 64 * kWaves;
 constexpr int kTileRows = 32 * kWaves;
-constexpr int kWLoads = kChunkBytes / 16 / kThreads;   // 16-byte pieces of a W chunk per thread
+#ifndef GEMM_STAGE
+#define GEMM_STAGE 2
+#endif
+constexpr int kStage = GEMM_STAGE;                 // K steps of W staged per barrier
+constexpr int kStageBytes = kStage * kChunkBytes;
+constexpr int kWLoads = kStageBytes / 16 / kThreads;   // 16-byte pieces of a W stage per thread
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
                                                             float *__restrict__ Y, int64_t ldy,
                                                             int64_t M)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kChunkBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStageBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = (int64_t)blockIdx.x * kTileRows + 32 * wave + (lane & 31);
     const bool row_ok = row < M;
@@ -144,15 +153,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-    // stage W chunk c into LDS buffer b: 24 KiB = 256 threads x 6 x 16 B, linear copy
+    // stage W stage s (kStage chunks of 24 KiB) into LDS buffer b: linear copy by all threads
     u32x4 wreg[kWLoads];
-    auto w_load = [&](int c) {
-        const u32x4 *src = (const u32x4 *)((const unsigned char *)wsp + (size_t)c * kChunkBytes);
+    auto w_load = [&](int st) {
+        const u32x4 *src = (const u32x4 *)((const unsigned char *)wsp + (size_t)st * kStageBytes);
 #pragma unroll
         for (int i = 0; i < kWLoads; ++i) wreg[i] = src[i * kThreads + tid];
     };
     auto w_store = [&](int b) {
-        u32x4 *dst = (u32x4 *)(lds + b * kChunkBytes);
+        u32x4 *dst = (u32x4 *)(lds + b * kStageBytes);
 #pragma unroll
         for (int i = 0; i < kWLoads; ++i) dst[i * kThreads + tid] = wreg[i];
     };
@@ -186,16 +195,27 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
     split_frag(ar[0][0], ar[0][1]);
 #pragma unroll
     for (int c = 0; c < kChunks; ++c) {
-        __syncthreads();   // chunk c is in lds[c & 1]; everyone is done with lds[(c + 1) & 1]
-        if (c + 1 < kChunks) w_load(c + 1);   // prefetch: W one step ahead, X two steps ahead
+        const int st = c / kStage;
+        if (c % kStage == 0) {
+            __syncthreads();   // W stage st is in lds[st & 1]; everyone is done with lds[(st + 1) & 1]
+            if ((st + 1) * kStage < kChunks) w_load(st + 1);   // prefetch the next W stage
+        }
         if (c + 2 < kChunks) a_fetch(c + 2, ar[(c + 2) % 3][0], ar[(c + 2) % 3][1]);
         const u32x4 Xh = Ah, Xm = Am, Xl = Al;
-        const unsigned char *buf = lds + (c & 1) * kChunkBytes;
+        const unsigned char *buf = lds + (st & 1) * kStageBytes + (c % kStage) * kChunkBytes;
+        // W fragments of column block nb+1 are read from LDS before the MFMAs of block nb issue
+        // (two register sets), so the LDS latency hides under the MFMA run
+        u32x4 Bf[2][3];
+        auto b_read = [&](int nb, u32x4 (&dst)[3]) {
+            dst[0] = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
+            dst[1] = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
+            dst[2] = *(const u32x4 *)(buf + ((2 * 8 + nb) * 64 + lane) * 16);
+        };
+        b_read(0, Bf[0]);
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
-            const u32x4 Bh = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
-            const u32x4 Bm = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
-            const u32x4 Bl = *(const u32x4 *)(buf + ((2 * 8 + nb) * 64 + lane) * 16);
+            if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
+            const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1], Bl = Bf[nb & 1][2];
             // W fragment as the MFMA "A" operand, X fragment as "B": the accumulator then holds
             // the TRANSPOSED 32x32 tile (lane = output row, 4 consecutive registers = 4
             // consecutive output columns), which stores as 16 bytes per lane
@@ -210,11 +230,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
             __builtin_amdgcn_s_setprio(0);
             acc[nb] = t;
         }
+        if (c % kStage == kStage - 1 && c + 1 < kChunks) w_store((st + 1) & 1);
         if (c + 1 < kChunks) {
-            w_store((c + 1) & 1);
             // split the NEXT step's X fragment here, behind this step's MFMA run, so that it
-            // overlaps the partner wave's MFMAs instead of idling the pipe right after the barrier
+            // overlaps the partner wave's MFMAs instead of idling the pipe right after the
+            // barrier; the empty asm makes the results opaque so the compiler cannot sink the
+            // split back across the barrier to its first use
             split_frag(ar[(c + 1) % 3][0], ar[(c + 1) % 3][1]);
+            asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
         }
     }
 
