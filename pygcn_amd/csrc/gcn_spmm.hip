@@ -635,15 +635,34 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ partial,
-                                                            float *__restrict__ colsum, int n_blocks,
-                                                            int F)
+// partial[n_blocks][F] -> colsum[F].  A 1024-thread block owns 32 columns; thread (g, c) adds the
+// partial rows g, g+32, g+64, ... of column c (4 loads in flight), then the 32 group sums are added
+// in group order through LDS: a fixed summation order, so the result is bitwise reproducible.
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float *__restrict__ partial,
+                                                             float *__restrict__ colsum, int n_blocks,
+                                                             int F)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * F + f];
-    colsum[f] = s;
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int f = blockIdx.x * 32 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (f < F) {
+        int b = g;
+        for (; b + 96 < n_blocks; b += 128) {
+            s0 += partial[(int64_t)b * F + f];
+            s1 += partial[(int64_t)(b + 32) * F + f];
+            s2 += partial[(int64_t)(b + 64) * F + f];
+            s3 += partial[(int64_t)(b + 96) * F + f];
+        }
+        for (; b < n_blocks; b += 32) s0 += partial[(int64_t)b * F + f];
+    }
+    red[g][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && f < F) {
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s += red[k][c];
+        colsum[f] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1006,7 +1025,7 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
         hipLaunchKernelGGL(bwd_colsum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
                            (const float *)nullptr, (float *)nullptr, (float *)workspace, n_rows, (int)F,
                            scale, rows_per_block);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 31) / 32)), dim3(1024), 0, s,
                        (const float *)workspace, colsum, (int)blocks, (int)F);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum launch");
