@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 3
+#define GCN_ABI_VERSION 4
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -138,6 +138,14 @@ typedef struct gcn_epilogue {
     int32_t relu;
     float dropout_p;     /* in [0, 1); 0 disables dropout */
     uint64_t seed;
+    /* Optional hint about the dense operand B (both NULL = none): b_row_nonzero[n_cols] holds 0
+     * for rows of B that are entirely zero, *b_nnz_rows their complement's count.  Such rows are
+     * not gathered (their products are zero anyway, so the result is unchanged); the hint is
+     * ignored on the device when 3/4 or more of the rows are non-zero.  Produced for free by
+     * gcn_relu_dropout_backward_colsum — the gradients of a semi-supervised loss
+     * (`nll_loss(output[idx_train], ...)`, pygcn/train.py) are non-zero on few rows. */
+    const uint8_t *b_row_nonzero;
+    const int32_t *b_nnz_rows;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */
@@ -160,11 +168,14 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
  * sums of grad_out; grad_pre is then ignored).  Deterministic (per-block partial rows added in
  * block order, no float atomics).  F must be a multiple of 4 with F/4 dividing 256
  * (4, 8, ..., 256, 512, 1024); scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F).
+ * Optional outputs (both or neither; F <= 256): row_nonzero[n_rows] = 1 where a row of the result
+ * has a non-zero element, *nnz_rows = how many — the B-operand hint of gcn_epilogue.
  */
 size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F);
 int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
-                                     void *workspace, size_t workspace_bytes, void *stream);
+                                     uint8_t *row_nonzero, int32_t *nnz_rows, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /*
  * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of

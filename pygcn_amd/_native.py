@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 3
+GCN_ABI_VERSION = 4
 GCN_DEFAULT_ITEM_COST = 64
 GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
@@ -37,7 +37,8 @@ class GcnCsrPlan(ctypes.Structure):
 class GcnEpilogue(ctypes.Structure):
     """Mirror of `struct gcn_epilogue` (include/gcn_spmm.h)."""
     _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32),
-                ("dropout_p", ctypes.c_float), ("seed", ctypes.c_uint64)]
+                ("dropout_p", ctypes.c_float), ("seed", ctypes.c_uint64),
+                ("b_row_nonzero", ctypes.c_void_p), ("b_nnz_rows", ctypes.c_void_p)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
@@ -114,8 +115,8 @@ def lib():
     L.gcn_relu_dropout_backward_colsum.restype = ctypes.c_int
     L.gcn_relu_dropout_backward_colsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
-                                                   ctypes.c_void_p]
+                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_workspace_bytes.argtypes = []
     L.gcn_gemm_xw256_f32.restype = ctypes.c_int

@@ -79,6 +79,9 @@ struct KParams {
     uint32_t drop_thresh;   // keep an element iff its 32 random bits >= drop_thresh (0: no dropout)
     float drop_scale;       // 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
+    const uint8_t *bflag;    // optional [n_cols]: 0 = row of B is entirely zero (skip its gather)
+    const int32_t *bnnz;     // optional device scalar: number of non-zero rows of B
+    int32_t n_cols;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -145,6 +148,15 @@ template <> struct Elem<bf16_t, 1> {
         return (bf16_t)(pack_bf16x2(x[0], 0.f) & 0xffffu);
     }
 };
+
+// Row flags of a row-sparse dense operand are used only when they can pay: a device-side count
+// (no host synchronisation) says fewer than 3/4 of the rows are non-zero.
+__device__ __forceinline__ bool use_row_flags(const KParams &p)
+{
+    if (p.bflag == nullptr || p.bnnz == nullptr) return false;
+    const int nz = __builtin_amdgcn_readfirstlane(*p.bnnz);
+    return (int64_t)nz * 4 < (int64_t)p.n_cols * 3;
+}
 
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float readlane_f(float v, int l)
@@ -241,6 +253,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     const uint32_t row_bytes = (uint32_t)p.F * (uint32_t)sizeof(T);
     int r = 0;
     int rend = ROWS ? readlane_i(rel_end, 0) : INT_MAX;
+    const bool flags = use_row_flags(p);   // wave-uniform
 
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
@@ -266,12 +279,16 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
             cv = colp[t + lane];
             vv = valp[t + lane];
         }
+        // row-sparse operand: one byte gather per tile tells which of the 64 rows are all-zero;
+        // their slots get num_records = 0 like the slots past the end of the tile (no traffic)
+        int fv = 1;
+        if (flags) fv = (lane < cnt) ? (int)p.bflag[cv] : 0;
         for (int k = 0; k < cnt; k += D) {
             // D row loads in flight, branch-free
             u32x4 x[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const bool ok = k + j < cnt;
+                const bool ok = (k + j < cnt) && (readlane_i(fv, k + j) != 0);
                 const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
                 x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
                                   ok ? row_bytes : 0u, ld_off_bytes);
@@ -349,7 +366,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__restrict__ col,
                                            const float *__restrict__ val, int64_t e0, int64_t e1,
-                                           int g, unsigned ld_off, float (&acc)[VEC])
+                                           int g, unsigned ld_off, float (&acc)[VEC],
+                                           bool flags = false)
 {
     typedef typename Elem<T, VEC>::Raw Raw;
     constexpr int G = kWave / LPR;
@@ -364,17 +382,19 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
             const bool ok = ee < e1;
             c[u] = ok ? col[ee] : 0;
             a[u] = ok ? val[ee] : 0.f;
+            if (flags && ok && p.bflag[c[u]] == 0) a[u] = 0.f, c[u] = -1;   // all-zero row: skip
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // entries past the end of the row point at row 0 (a harmless cached read); their
             // products are skipped below, so non-finite values there cannot leak in
-            x[u] = *(const Raw *)((const char *)p.B + (int64_t)c[u] * ldb_bytes + ld_off);
+            x[u] = *(const Raw *)((const char *)p.B + (int64_t)(c[u] < 0 ? 0 : c[u]) * ldb_bytes +
+                                  ld_off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t ee = e + (int64_t)u * G + g;
-            if (ee < e1) {
+            if (ee < e1 && c[u] >= 0) {
                 float xf[VEC];
                 Elem<T, VEC>::unpack(x[u], xf);
 #pragma unroll
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     const bool act = f < p.F;
     const unsigned ld_off = act ? (unsigned)f * (unsigned)sizeof(T) : 0u;
     const IdxT *__restrict__ rp = (const IdxT *)p.rowptr;
+    const bool flags = use_row_flags(p);   // wave-uniform
 
     float acc[VEC], bias[VEC];
 #pragma unroll
@@ -416,7 +437,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
         const int row = p.chunk_row[item];
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
-        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
+        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
         if (act && g == 0) {
             float *dst = p.partial + (int64_t)item * p.F + f;
 #pragma unroll
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
             const int64_t e1 = (int64_t)rp[r + 1];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-            narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc);
+            narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
             store_out<T, VEC>(p, (int64_t)r, f, act && g == 0, acc, bias);
             e0 = e1;
         }
@@ -474,6 +495,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     if (lane < ne) {
         cv = p.col[ea + lane];
         vv = p.val[ea + lane];
+        if (flags && p.bflag[cv] == 0) vv = 0.f, cv = -1;   // all-zero row of B: skip its gather
     }
     const int up = __shfl_up(rel_end, 1, kWave);
     const int rel_start = (lane == 0) ? 0 : up;
@@ -506,8 +528,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     const int idx = e0[ru] + j + u;
-                    const bool ok = idx < e1[ru];
                     const int c = __shfl(cv, idx & (kWave - 1), kWave);
+                    const bool ok = idx < e1[ru] && c >= 0;
                     const float a = __shfl(vv, idx & (kWave - 1), kWave);
                     av[ru][u] = ok ? a : 0.f;
                     Raw z = {};
@@ -521,13 +543,11 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
             for (int ru = 0; ru < RU; ++ru) {
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
-                    if (e0[ru] + j + u < e1[ru]) {   // skip: never multiply an unloaded slot
-                        float xf[VEC];
-                        Elem<T, VEC>::unpack(x[ru][u], xf);
+                    // slots that were not loaded hold zeros with weight 0: adding them is exact
+                    float xf[VEC];
+                    Elem<T, VEC>::unpack(x[ru][u], xf);
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i)
-                            a2[ru][i] = fmaf(av[ru][u], xf[i], a2[ru][i]);
-                    }
+                    for (int i = 0; i < VEC; ++i) a2[ru][i] = fmaf(av[ru][u], xf[i], a2[ru][i]);
                 }
             }
         }
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
         const int s0 = readlane_i(rel_start, rr), s1 = readlane_i(rel_end, rr);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc);
+        narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc, flags);
         store_out<T, VEC>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
     }
 }
@@ -606,7 +626,9 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
                                                          const float *__restrict__ out,
                                                          float *__restrict__ grad_pre,
                                                          float *__restrict__ partial, int64_t n_rows,
-                                                         int F, float scale, int rows_per_block)
+                                                         int F, float scale, int rows_per_block,
+                                                         uint8_t *__restrict__ rowflag,
+                                                         int32_t *__restrict__ nnz_rows)
 {
     __shared__ float red[256 * 4];
     const int CG = F >> 2, RL = 256 / CG;         // column groups, row lanes
@@ -614,6 +636,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(r0 + (int64_t)rows_per_block, n_rows);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int nz_count = 0;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
         const int64_t off = r * F + 4 * cg;
         f32x4 g = *(const f32x4 *)(grad_out + off);
@@ -626,6 +649,25 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
             *(f32x4 *)(grad_pre + off) = g;
         }
         acc += g;
+        if (rowflag != nullptr) {
+            // a row lives in CG <= 64 consecutive lanes of one wave (all active or all inactive
+            // together): its non-zero flag is a slice of the wave's ballot over the active lanes;
+            // the row's first lane writes the byte
+            const unsigned long long b = __ballot(g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f);
+            const int lane = threadIdx.x & 63;
+            if (cg == 0) {
+                const unsigned long long m = CG >= 64 ? ~0ull : (((1ull << CG) - 1) << (lane & ~(CG - 1)));
+                const bool nz = (b & m) != 0;
+                rowflag[r] = nz ? 1 : 0;
+                nz_count += nz ? 1 : 0;
+            }
+        }
+    }
+    if (rowflag != nullptr) {
+        // one atomic per wave: lanes that own rows hold their counts
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nz_count += __shfl_xor(nz_count, off, 64);
+        if ((threadIdx.x & 63) == 0 && nz_count) atomicAdd(nnz_rows, nz_count);
     }
     *(f32x4 *)(red + threadIdx.x * 4) = acc;
     __syncthreads();
@@ -929,6 +971,10 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.drop_scale = 1.f / (1.f - drop_p);
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
+    kp.bflag = ep ? ep->b_row_nonzero : nullptr;
+    kp.bnnz = ep ? ep->b_nnz_rows : nullptr;
+    if (kp.bflag == nullptr || kp.bnnz == nullptr) kp.bflag = nullptr, kp.bnnz = nullptr;
+    kp.n_cols = (int32_t)std::min<int64_t>(plan->n_cols, INT32_MAX);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GCN_DTYPE_F32) return spmm_typed<float, 4>(plan, kp, s);
     return spmm_typed<bf16_t, 8>(plan, kp, s);
@@ -943,6 +989,8 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.relu = relu;
     ep.dropout_p = 0.f;
     ep.seed = 0;
+    ep.b_row_nonzero = nullptr;
+    ep.b_nnz_rows = nullptr;
     return gcn_spmm_csr_ep(plan, dtype, B, ldb, C, ldc, F, &ep, workspace, workspace_bytes, stream);
 }
 
@@ -999,14 +1047,22 @@ size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F)
 
 int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
-                                     void *workspace, size_t workspace_bytes, void *stream)
+                                     uint8_t *row_nonzero, int32_t *nnz_rows, void *workspace,
+                                     size_t workspace_bytes, void *stream)
 {
+    if ((row_nonzero == nullptr) != (nnz_rows == nullptr))
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: row_nonzero and nnz_rows go together");
+    if (row_nonzero != nullptr && F > 256) { row_nonzero = nullptr; nnz_rows = nullptr; }   // row > 1 wave
     if (n_rows < 0 || !colsum_shape_ok(F))
         return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of 4 with "
                                   "F/4 dividing 256");
     if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))
         return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
+    if (nnz_rows != nullptr) {
+        hipError_t e = hipMemsetAsync(nnz_rows, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
+    }
     if (n_rows == 0) {
         hipError_t e = hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), s);
         return e == hipSuccess ? 0 : fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
@@ -1020,11 +1076,12 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
     const int rows_per_block = (int)((n_rows + blocks - 1) / blocks);
     if (out != nullptr)
         hipLaunchKernelGGL(bwd_colsum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
-                           out, grad_pre, (float *)workspace, n_rows, (int)F, scale, rows_per_block);
+                           out, grad_pre, (float *)workspace, n_rows, (int)F, scale, rows_per_block,
+                           row_nonzero, nnz_rows);
     else
         hipLaunchKernelGGL(bwd_colsum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
                            (const float *)nullptr, (float *)nullptr, (float *)workspace, n_rows, (int)F,
-                           scale, rows_per_block);
+                           scale, rows_per_block, row_nonzero, nnz_rows);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 31) / 32)), dim3(1024), 0, s,
                        (const float *)workspace, colsum, (int)blocks, (int)F);
     hipError_t e = hipGetLastError();

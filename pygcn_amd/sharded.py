@@ -263,8 +263,10 @@ class ShardedSpMMFunction(torch.autograd.Function):
         grad_support = None
         out = ctx.saved_tensors[0] if ctx.relu else None
         # grad_bias is this rank's partial sum: summed over ranks by allreduce_grads
-        grad_out, grad_bias = ctx.sg._bwd(grad_out, out, ctx.relu, ctx.scale,
-                                          ctx.has_bias and ctx.needs_input_grad[2])
+        # (the row-sparsity hint is not used here: the operand of the local product is the
+        #  exchanged buffer, whose halo rows carry no flags)
+        grad_out, grad_bias, _ = ctx.sg._bwd(grad_out, out, ctx.relu, ctx.scale,
+                                             ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
         return None, grad_support, grad_bias, None, None, None

@@ -26,10 +26,13 @@ def set_timing_records(records):
     _timing_records = records
 
 
-def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0):
+def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
+             b_hint=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
-    (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50)."""
+    (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row_nonzero
+    uint8 [n_cols], nnz_rows int32 scalar) device tensors from backward_with_colsum: rows of B
+    flagged all-zero are not gathered (same result, less traffic)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -64,7 +67,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         ep = _native.GcnEpilogue(bias.data_ptr() if bias is not None else None, int(bool(relu)),
-                                 float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF)
+                                 float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                 b_hint[0].data_ptr() if b_hint is not None else None,
+                                 b_hint[1].data_ptr() if b_hint is not None else None)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -92,8 +97,10 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
 
 
 def backward_with_colsum(grad_out, out=None, scale=1.0):
-    """(grad_pre, column sums of grad_pre) in ONE pass over fp32 [N, F] tensors
-    (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
+    """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 [N, F] tensors
+    (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.  The
+    hint — (row_nonzero uint8 [N], nnz_rows int32 [1]) or None when F > 256 — can be handed to
+    spmm_csr(b_hint=...) when grad_pre is the dense operand of the following product.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
     _require_cuda(grad_out, "grad_out")
@@ -107,20 +114,26 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
     n, F = grad_out.shape
     grad_pre = torch.empty_like(grad_out) if out is not None else grad_out
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
+    hint = None
+    if F <= 256:   # a row then lives inside one wavefront of the kernel: flags come for free
+        hint = (torch.empty(n, dtype=torch.uint8, device=grad_out.device),
+                torch.empty(1, dtype=torch.int32, device=grad_out.device))
     ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
         rc = L.gcn_relu_dropout_backward_colsum(
             grad_out.data_ptr(), out.data_ptr() if out is not None else None,
             grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
+            hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None,
             ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_relu_dropout_backward_colsum")
-    return grad_pre, colsum
+    return grad_pre, colsum, hint
 
 
 def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):
     """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask and
-    (optionally) produce the bias gradient, in one HIP pass when the shape allows."""
+    (optionally) produce the bias gradient, in one HIP pass when the shape allows.  Returns
+    (grad_pre, grad_bias, row-sparsity hint or None)."""
     grad_bias = None
     if want_bias:
         fused = backward_with_colsum(grad_out.contiguous(), out if relu else None, scale)
@@ -130,7 +143,7 @@ def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):
         grad_out = relu_dropout_backward(grad_out, out, scale)
     if want_bias:
         grad_bias = grad_out.sum(0)
-    return grad_out, grad_bias
+    return grad_out, grad_bias, None
 
 
 def next_dropout_seed():
@@ -164,10 +177,12 @@ class SpMMFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         grad_B = None
         out = ctx.saved_tensors[0] if ctx.relu else None
-        grad_out, grad_bias = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale,
-                                                 ctx.has_bias and ctx.needs_input_grad[2])
+        grad_out, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale,
+                                                       ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
-            grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd")
+            # gradients of a loss on few labelled rows are non-zero on few rows: the hint lets the
+            # transpose product skip the all-zero rows of its dense operand
+            grad_B = spmm_csr(ctx.graph.t(), grad_out.contiguous(), tag="bwd", b_hint=hint)
         return None, grad_B, grad_bias, None, None, None
 
 

@@ -48,7 +48,7 @@ def _cpu_bwd(grad_out, out, relu, scale, want_bias):
     """CPU stand-in for the HIP backward pass (mask through out > 0, bias gradient)."""
     if relu:
         grad_out = torch.where(out > 0, grad_out * scale, torch.zeros_like(grad_out))
-    return grad_out, (grad_out.sum(0) if want_bias else None)
+    return grad_out, (grad_out.sum(0) if want_bias else None), None
 
 
 def _worker(rank, world, port, n, n_edges, out_dir, exchange):

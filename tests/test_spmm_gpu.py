@@ -564,16 +564,54 @@ def test_backward_with_colsum_matches_torch(dev, F):
         gen = torch.Generator(device=dev).manual_seed(n + F)
         go = torch.randn(n, F, generator=gen, device=dev)
         out = torch.randn(n, F, generator=gen, device=dev)
-        gp, cs = backward_with_colsum(go, out, 1.5)
+        go[::3] = 0                               # a third of the rows entirely zero
+        gp, cs, hint = backward_with_colsum(go, out, 1.5)
         ref = torch.where(out > 0, go * 1.5, torch.zeros_like(go))
         assert torch.equal(gp, ref)
+        if F <= 256:
+            flags, cnt = hint
+            assert torch.equal(flags.bool(), (ref != 0).any(1)) and int(cnt) == int(flags.sum())
+        else:
+            assert hint is None
         ref_cs = ref.double().sum(0)
         assert float((cs.double() - ref_cs).abs().max()) <= 1e-5 * float(ref.abs().sum(0).max()) + 1e-6
-        gp2, cs2 = backward_with_colsum(go, out, 1.5)
+        gp2, cs2, _ = backward_with_colsum(go, out, 1.5)
         assert torch.equal(cs, cs2)
-        gq, cq = backward_with_colsum(go, None, 1.0)
+        gq, cq, hq = backward_with_colsum(go, None, 1.0)
         assert gq is go
+        if F <= 256:
+            assert torch.equal(hq[0].bool(), (go != 0).any(1))
         assert float((cq.double() - go.double().sum(0)).abs().max()) <= \
             1e-5 * float(go.abs().sum(0).max()) + 1e-6
     assert backward_with_colsum(torch.randn(10, 7, device=dev)) is None
     assert backward_with_colsum(torch.randn(10, 256, device=dev).bfloat16()) is None
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (512, torch.float32), (64, torch.float32),
+                                     (16, torch.float32), (7, torch.float32), (128, torch.bfloat16)])
+@pytest.mark.parametrize("density", [0.02, 0.5, 0.9])
+def test_row_sparse_operand_hint_changes_nothing_but_traffic(oracle, dev, F, dtype, density):
+    """Rows of B flagged all-zero are not gathered: the product must be identical with and
+    without the hint, on every kernel path, whether the device-side count enables the flags
+    (density < 3/4) or not; stale flags on non-zero rows are the caller's bug and not tested."""
+    from pygcn_amd import spmm_csr
+    a = _skewed_csr(oracle, 2500, 2200, 6, seed=int(F + 100 * density), empties=100,
+                    hubs=((3, 1200), (900, 300), (901, 40)))
+    g = _graph(a, dev)
+    gen = torch.Generator(device=dev).manual_seed(F)
+    B = torch.randn(2200, F, generator=gen, device=dev)
+    keep = torch.rand(2200, generator=gen, device=dev) < density
+    B = (B * keep[:, None]).to(dtype)
+    flags = (B != 0).any(1).to(torch.uint8)
+    cnt = flags.sum().to(torch.int32).reshape(1)
+    plain = spmm_csr(g, B)
+    hinted = spmm_csr(g, B, b_hint=(flags, cnt))
+    assert torch.equal(plain, hinted)
+    ref = a.matmul(B.float().cpu().numpy())
+    assert_normwise(hinted.float().cpu(), ref, 2.0 ** -8 if dtype == torch.bfloat16 else TOL, "hinted")
+    # non-finite values in a flagged-NONZERO row still propagate
+    if dtype == torch.float32 and density < 0.75:
+        B2 = B.clone()
+        r = int(torch.nonzero(keep)[0])
+        B2[r, 0] = float("inf")
+        assert torch.equal(spmm_csr(g, B2).isfinite(), spmm_csr(g, B2, b_hint=(flags, cnt)).isfinite())
