@@ -240,7 +240,7 @@ __device__ __forceinline__ u32x4 row_load16(uint64_t base, uint32_t nbytes, uint
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
 }
 
-template <typename T, int VEC, int D, bool ROWS>
+template <typename T, int VEC, int D, bool ROWS, bool FLAGS>
 __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__restrict__ colp,
                                             const float *__restrict__ valp, int ne, int lane,
                                             unsigned ld_off_bytes, float (&acc)[VEC],
@@ -253,8 +253,8 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     const uint32_t row_bytes = (uint32_t)p.F * (uint32_t)sizeof(T);
     int r = 0;
     int rend = ROWS ? readlane_i(rel_end, 0) : INT_MAX;
-    const bool flags = use_row_flags(p);   // wave-uniform
-
+    const bool flags = FLAGS && use_row_flags(p);   // wave-uniform; FLAGS = false: dense operand,
+                                                    // the flag code is compiled out
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
             while (e >= rend) {   // row finished (loop: rows without stored entries follow)
@@ -282,13 +282,13 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
         // row-sparse operand: one byte gather per tile tells which of the 64 rows are all-zero;
         // their slots get num_records = 0 like the slots past the end of the tile (no traffic)
         int fv = 1;
-        if (flags) fv = (lane < cnt) ? (int)p.bflag[cv] : 0;
+        if (FLAGS && flags) fv = (lane < cnt) ? (int)p.bflag[cv] : 0;
         for (int k = 0; k < cnt; k += D) {
             // D row loads in flight, branch-free
             u32x4 x[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const bool ok = (k + j < cnt) && (readlane_i(fv, k + j) != 0);
+                const bool ok = (k + j < cnt) && (!FLAGS || readlane_i(fv, k + j) != 0);
                 const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
                 x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
                                   ok ? row_bytes : 0u, ld_off_bytes);
@@ -308,7 +308,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
 }
 
-template <typename T, int VEC, typename IdxT, int D>
+template <typename T, int VEC, typename IdxT, int D, bool FLAGS>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParams p)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
         const int row = p.chunk_row[item];
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
-        wide_stream<T, VEC, D, false>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
+        wide_stream<T, VEC, D, false, FLAGS>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
                                       ld_off_bytes, acc, 0, 0, 0, f, act, bias);
         if (act) {
             float *dst = p.partial + (int64_t)item * p.F + f;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
 #pragma unroll
         for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
     }
-    wide_stream<T, VEC, D, true>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
+    wide_stream<T, VEC, D, true, FLAGS>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
                                  nr, (int64_t)ra, f, act, bias);
 }
 
@@ -739,12 +739,18 @@ template <typename T, int VEC>
 void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
     constexpr int D = 8;
-    if (is64)
-        hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D>), grid,
-                           dim3(kWave * kWavesPerBlock), 0, s, kp);
-    else
-        hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D>), grid,
-                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+    const dim3 block(kWave * kWavesPerBlock);
+    if (kp.bflag != nullptr) {   // row-sparse operand hint: the variant that reads the row flags
+        if (is64)
+            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D, true>), grid, block, 0, s, kp);
+        else
+            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D, true>), grid, block, 0, s, kp);
+    } else {
+        if (is64)
+            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D, false>), grid, block, 0, s, kp);
+        else
+            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D, false>), grid, block, 0, s, kp);
+    }
 }
 
 int next_pow2(int v)
