@@ -138,13 +138,14 @@ typedef struct gcn_epilogue {
     int32_t relu;
     float dropout_p;     /* in [0, 1); 0 disables dropout */
     uint64_t seed;
-    /* Optional hint about the dense operand B (both NULL = none): b_row_nonzero[n_cols] holds 0
-     * for rows of B that are entirely zero, *b_nnz_rows their complement's count.  Such rows are
+    /* Optional hint about the dense operand B (both NULL = none): bit c of the bitmap
+     * b_row_nonzero[ceil(n_cols/32)] is clear for rows of B that are entirely zero, *b_nnz_rows
+     * counts the rows whose bit is set.  Such rows are
      * not gathered (their products are zero anyway, so the result is unchanged); the hint is
      * ignored on the device when 3/4 or more of the rows are non-zero.  Produced for free by
      * gcn_relu_dropout_backward_colsum — the gradients of a semi-supervised loss
      * (`nll_loss(output[idx_train], ...)`, pygcn/train.py) are non-zero on few rows. */
-    const uint8_t *b_row_nonzero;
+    const uint32_t *b_row_nonzero;
     const int32_t *b_nnz_rows;
 } gcn_epilogue;
 
@@ -168,13 +169,14 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
  * sums of grad_out; grad_pre is then ignored).  Deterministic (per-block partial rows added in
  * block order, no float atomics).  F must be a multiple of 4 with F/4 dividing 256
  * (4, 8, ..., 256, 512, 1024); scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F).
- * Optional outputs (both or neither; F <= 256): row_nonzero[n_rows] = 1 where a row of the result
- * has a non-zero element, *nnz_rows = how many — the B-operand hint of gcn_epilogue.
+ * Optional outputs (both or neither; F <= 256): bit r of row_bits[ceil(n_rows/32)] is set where
+ * row r of the result has a non-zero element, *nnz_rows = how many — the B-operand hint of
+ * gcn_epilogue.
  */
 size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F);
 int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
-                                     uint8_t *row_nonzero, int32_t *nnz_rows, void *workspace,
+                                     uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
                                      size_t workspace_bytes, void *stream);
 
 /*

@@ -79,7 +79,7 @@ struct KParams {
     uint32_t drop_thresh;   // keep an element iff its 32 random bits >= drop_thresh (0: no dropout)
     float drop_scale;       // 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
-    const uint8_t *bflag;    // optional [n_cols]: 0 = row of B is entirely zero (skip its gather)
+    const uint32_t *bflag;   // optional bitmap [ceil(n_cols/32)]: bit c clear = row c of B is all zero
     const int32_t *bnnz;     // optional device scalar: number of non-zero rows of B
     int32_t n_cols;
 };
@@ -156,6 +156,11 @@ __device__ __forceinline__ bool use_row_flags(const KParams &p)
     if (p.bflag == nullptr || p.bnnz == nullptr) return false;
     const int nz = __builtin_amdgcn_readfirstlane(*p.bnnz);
     return (int64_t)nz * 4 < (int64_t)p.n_cols * 3;
+}
+
+__device__ __forceinline__ bool row_bit(const uint32_t *__restrict__ bits, int c)
+{
+    return (bits[c >> 5] >> (c & 31)) & 1u;
 }
 
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -282,7 +287,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
         // row-sparse operand: one byte gather per tile tells which of the 64 rows are all-zero;
         // their slots get num_records = 0 like the slots past the end of the tile (no traffic)
         int fv = 1;
-        if (FLAGS && flags) fv = (lane < cnt) ? (int)p.bflag[cv] : 0;
+        if (FLAGS && flags) fv = (lane < cnt) ? (int)row_bit(p.bflag, cv) : 0;
         for (int k = 0; k < cnt; k += D) {
             // D row loads in flight, branch-free
             u32x4 x[D];
@@ -382,7 +387,7 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
             const bool ok = ee < e1;
             c[u] = ok ? col[ee] : 0;
             a[u] = ok ? val[ee] : 0.f;
-            if (flags && ok && p.bflag[c[u]] == 0) a[u] = 0.f, c[u] = -1;   // all-zero row: skip
+            if (flags && ok && !row_bit(p.bflag, c[u])) a[u] = 0.f, c[u] = -1;   // all-zero row: skip
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     if (lane < ne) {
         cv = p.col[ea + lane];
         vv = p.val[ea + lane];
-        if (flags && p.bflag[cv] == 0) vv = 0.f, cv = -1;   // all-zero row of B: skip its gather
+        if (flags && !row_bit(p.bflag, cv)) vv = 0.f, cv = -1;   // all-zero row of B: skip its gather
     }
     const int up = __shfl_up(rel_end, 1, kWave);
     const int rel_start = (lane == 0) ? 0 : up;
@@ -675,6 +680,21 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
         for (int k = 1; k < RL; ++k) acc += *(const f32x4 *)(red + (k * CG + cg) * 4);   // fixed order
         *(f32x4 *)(partial + (int64_t)blockIdx.x * F + 4 * cg) = acc;
     }
+}
+
+// per-row bytes -> bitmap words (1 bit per row; fits the XCD L2 where the byte table does not)
+__global__ __launch_bounds__(256) void pack_row_flags_kernel(const uint8_t *__restrict__ bytes,
+                                                             uint32_t *__restrict__ bits, int64_t n_rows)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_words = (n_rows + 31) >> 5;
+    if (w >= n_words) return;
+    uint32_t v = 0;
+    const int64_t r0 = w << 5;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i)
+        if (r0 + i < n_rows && bytes[r0 + i]) v |= 1u << i;
+    bits[w] = v;
 }
 
 // partial[n_blocks][F] -> colsum[F].  A 1024-thread block owns 32 columns; thread (g, c) adds the
@@ -1048,17 +1068,18 @@ size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F)
 {
     if (n_rows <= 0 || !colsum_shape_ok(F)) return 0;
     const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
-    return (size_t)blocks * (size_t)F * sizeof(float);
+    // partial column sums + one byte per row (staging for the row bitmap)
+    return (size_t)blocks * (size_t)F * sizeof(float) + (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
 int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
-                                     uint8_t *row_nonzero, int32_t *nnz_rows, void *workspace,
+                                     uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
                                      size_t workspace_bytes, void *stream)
 {
-    if ((row_nonzero == nullptr) != (nnz_rows == nullptr))
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: row_nonzero and nnz_rows go together");
-    if (row_nonzero != nullptr && F > 256) { row_nonzero = nullptr; nnz_rows = nullptr; }   // row > 1 wave
+    if ((row_bits == nullptr) != (nnz_rows == nullptr))
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: row_bits and nnz_rows go together");
+    if (row_bits != nullptr && F > 256) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
     if (n_rows < 0 || !colsum_shape_ok(F))
         return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of 4 with "
                                   "F/4 dividing 256");
@@ -1080,6 +1101,8 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
         return fail(GCN_E_ALIGN, "gcn_relu_dropout_backward_colsum: 16-byte alignment required");
     const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
     const int rows_per_block = (int)((n_rows + blocks - 1) / blocks);
+    uint8_t *row_nonzero = row_bits ? (uint8_t *)workspace + (size_t)blocks * (size_t)F * sizeof(float)
+                                    : nullptr;
     if (out != nullptr)
         hipLaunchKernelGGL(bwd_colsum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
                            out, grad_pre, (float *)workspace, n_rows, (int)F, scale, rows_per_block,
@@ -1090,6 +1113,9 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
                            scale, rows_per_block, row_nonzero, nnz_rows);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 31) / 32)), dim3(1024), 0, s,
                        (const float *)workspace, colsum, (int)blocks, (int)F);
+    if (row_bits != nullptr)
+        hipLaunchKernelGGL(pack_row_flags_kernel, dim3((unsigned)((((n_rows + 31) >> 5) + 255) / 256)),
+                           dim3(256), 0, s, (const uint8_t *)row_nonzero, row_bits, n_rows);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum launch");
     return 0;

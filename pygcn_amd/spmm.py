@@ -30,9 +30,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
              b_hint=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
-    (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row_nonzero
-    uint8 [n_cols], nnz_rows int32 scalar) device tensors from backward_with_colsum: rows of B
-    flagged all-zero are not gathered (same result, less traffic)."""
+    (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
+    int32 [ceil(n_cols/32)], nnz_rows int32 [1]) device tensors from backward_with_colsum (or
+    row_bitmap()): rows of B whose bit is clear are not gathered (same result, less traffic)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -99,7 +99,7 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
 def backward_with_colsum(grad_out, out=None, scale=1.0):
     """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 [N, F] tensors
     (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.  The
-    hint — (row_nonzero uint8 [N], nnz_rows int32 [1]) or None when F > 256 — can be handed to
+    hint — (row bitmap int32 [ceil(N/32)], nnz_rows int32 [1]) or None when F > 256 — can be handed to
     spmm_csr(b_hint=...) when grad_pre is the dense operand of the following product.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
@@ -116,7 +116,7 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
     hint = None
     if F <= 256:   # a row then lives inside one wavefront of the kernel: flags come for free
-        hint = (torch.empty(n, dtype=torch.uint8, device=grad_out.device),
+        hint = (torch.empty((n + 31) // 32, dtype=torch.int32, device=grad_out.device),   # bitmap
                 torch.empty(1, dtype=torch.int32, device=grad_out.device))
     ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
@@ -128,6 +128,19 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
             ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_relu_dropout_backward_colsum")
     return grad_pre, colsum, hint
+
+
+def row_bitmap(B):
+    """(bitmap, count) hint for a dense operand: bit r set iff row r of B has a non-zero element
+    (torch ops; the backward pass gets the same thing for free from backward_with_colsum)."""
+    nz = (B != 0).any(1)
+    n = nz.numel()
+    pad = (-n) % 32
+    if pad:
+        nz = torch.cat([nz, torch.zeros(pad, dtype=torch.bool, device=nz.device)])
+    w = (nz.view(-1, 32).to(torch.int64) << torch.arange(32, device=nz.device)).sum(1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+    return w, nz.sum().to(torch.int32).reshape(1)
 
 
 def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):

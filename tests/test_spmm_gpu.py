@@ -569,8 +569,10 @@ def test_backward_with_colsum_matches_torch(dev, F):
         ref = torch.where(out > 0, go * 1.5, torch.zeros_like(go))
         assert torch.equal(gp, ref)
         if F <= 256:
-            flags, cnt = hint
-            assert torch.equal(flags.bool(), (ref != 0).any(1)) and int(cnt) == int(flags.sum())
+            from pygcn_amd.spmm import row_bitmap
+            bits, cnt = hint
+            rb, rc = row_bitmap(ref)
+            assert torch.equal(bits, rb) and int(cnt) == int(rc) == int((ref != 0).any(1).sum())
         else:
             assert hint is None
         ref_cs = ref.double().sum(0)
@@ -580,7 +582,8 @@ def test_backward_with_colsum_matches_torch(dev, F):
         gq, cq, hq = backward_with_colsum(go, None, 1.0)
         assert gq is go
         if F <= 256:
-            assert torch.equal(hq[0].bool(), (go != 0).any(1))
+            from pygcn_amd.spmm import row_bitmap
+            assert torch.equal(hq[0], row_bitmap(go)[0])
         assert float((cq.double() - go.double().sum(0)).abs().max()) <= \
             1e-5 * float(go.abs().sum(0).max()) + 1e-6
     assert backward_with_colsum(torch.randn(10, 7, device=dev)) is None
@@ -602,8 +605,8 @@ def test_row_sparse_operand_hint_changes_nothing_but_traffic(oracle, dev, F, dty
     B = torch.randn(2200, F, generator=gen, device=dev)
     keep = torch.rand(2200, generator=gen, device=dev) < density
     B = (B * keep[:, None]).to(dtype)
-    flags = (B != 0).any(1).to(torch.uint8)
-    cnt = flags.sum().to(torch.int32).reshape(1)
+    from pygcn_amd.spmm import row_bitmap
+    flags, cnt = row_bitmap(B)
     plain = spmm_csr(g, B)
     hinted = spmm_csr(g, B, b_hint=(flags, cnt))
     assert torch.equal(plain, hinted)
