@@ -286,14 +286,35 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
         }
         // row-sparse operand: one byte gather per tile tells which of the 64 rows are all-zero;
         // their slots get num_records = 0 like the slots past the end of the tile (no traffic)
-        int fv = 1;
-        if (FLAGS && flags) fv = (lane < cnt) ? (int)row_bit(p.bflag, cv) : 0;
+        if (FLAGS && flags) {
+            // row-sparse operand: one bitmap probe per lane tells which of the tile's rows of B are
+            // all-zero; only the stored entries whose bit is set are visited (ascending order, so
+            // the row bookkeeping of consume() is unchanged), D at a time
+            const int fv = (lane < cnt) ? (int)row_bit(p.bflag, cv) : 0;
+            unsigned long long m = __ballot(fv != 0);
+            while (m) {
+                int kk[D];
+                u32x4 x[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    kk[j] = m ? (int)__builtin_ctzll(m) : -1;
+                    m &= m - 1;   // (0 stays 0)
+                    const int c = readlane_i(cv, kk[j] < 0 ? 0 : kk[j]);
+                    x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
+                                      kk[j] >= 0 ? row_bytes : 0u, ld_off_bytes);
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (kk[j] >= 0) consume(t + kk[j], x[j], readlane_f(vv, kk[j]));
+            }
+            continue;
+        }
         for (int k = 0; k < cnt; k += D) {
             // D row loads in flight, branch-free
             u32x4 x[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                const bool ok = (k + j < cnt) && (!FLAGS || readlane_i(fv, k + j) != 0);
+                const bool ok = k + j < cnt;
                 const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
                 x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
                                   ok ? row_bytes : 0u, ld_off_bytes);
