@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 4
+#define GCN_ABI_VERSION 5
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -147,6 +147,13 @@ typedef struct gcn_epilogue {
      * (`nll_loss(output[idx_train], ...)`, pygcn/train.py) are non-zero on few rows. */
     const uint32_t *b_row_nonzero;
     const int32_t *b_nnz_rows;
+    /* Optional second block of the dense operand (NULL = B is one block): rows b_split, b_split+1,
+     * ... of B are read from b2 (row-major, leading dimension ldb2, same dtype) instead.  Lets the
+     * sharded path multiply with [own activation rows | received halo rows] without copying the
+     * own rows next to the halo buffer. */
+    const void *b2;
+    int64_t ldb2;
+    int64_t b_split;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

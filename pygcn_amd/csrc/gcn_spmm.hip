@@ -79,6 +79,9 @@ struct KParams {
     uint32_t drop_thresh;   // keep an element iff its 32 random bits >= drop_thresh (0: no dropout)
     float drop_scale;       // 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
+    const void *B2;          // optional second block of B: rows >= b_split live here (ldb2)
+    int64_t ldb2;
+    int32_t b_split;         // INT32_MAX when B is one block
     const uint32_t *bflag;   // optional bitmap [ceil(n_cols/32)]: bit c clear = row c of B is all zero
     const int32_t *bnnz;     // optional device scalar: number of non-zero rows of B
     int32_t n_cols;
@@ -255,7 +258,14 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     typedef typename Elem<T, VEC>::Raw Raw;
     static_assert(sizeof(Raw) == 16, "wide kernel moves 16 bytes per lane");
     const uint32_t ldb_bytes = (uint32_t)(p.ldb * (int64_t)sizeof(T));   // < 4 GiB, host-checked
+    const uint32_t ldb2_bytes = (uint32_t)(p.ldb2 * (int64_t)sizeof(T));
     const uint32_t row_bytes = (uint32_t)p.F * (uint32_t)sizeof(T);
+    // row c of the dense operand: in B below the split, in B2 (rebased) from the split on; all
+    // scalar arithmetic (the sharded path keeps a rank's own rows and its halo rows apart)
+    auto row_base = [&](int c) -> uint64_t {
+        return c < p.b_split ? (uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes
+                             : (uint64_t)p.B2 + (uint64_t)(uint32_t)(c - p.b_split) * ldb2_bytes;
+    };
     int r = 0;
     int rend = ROWS ? readlane_i(rel_end, 0) : INT_MAX;
     const bool flags = FLAGS && use_row_flags(p);   // wave-uniform; FLAGS = false: dense operand,
@@ -300,8 +310,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
                     kk[j] = m ? (int)__builtin_ctzll(m) : -1;
                     m &= m - 1;   // (0 stays 0)
                     const int c = readlane_i(cv, kk[j] < 0 ? 0 : kk[j]);
-                    x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
-                                      kk[j] >= 0 ? row_bytes : 0u, ld_off_bytes);
+                    x[j] = row_load16(row_base(c), kk[j] >= 0 ? row_bytes : 0u, ld_off_bytes);
                 }
 #pragma unroll
                 for (int j = 0; j < D; ++j)
@@ -316,8 +325,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
             for (int j = 0; j < D; ++j) {
                 const bool ok = k + j < cnt;
                 const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
-                x[j] = row_load16((uint64_t)p.B + (uint64_t)(uint32_t)c * ldb_bytes,
-                                  ok ? row_bytes : 0u, ld_off_bytes);
+                x[j] = row_load16(row_base(c), ok ? row_bytes : 0u, ld_off_bytes);
             }
 #pragma unroll
             for (int j = 0; j < D; ++j)
@@ -389,6 +397,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
 // so G = 64/LPR stored entries of the SAME output row travel side by side in one wave
 // instruction; the G partial sums meet in a wavefront shuffle reduction.
 // ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ const char *narrow_row_ptr(const KParams &p, int c)
+{
+    return c < p.b_split ? (const char *)p.B + (int64_t)c * (p.ldb * (int64_t)sizeof(T))
+                         : (const char *)p.B2 + (int64_t)(c - p.b_split) * (p.ldb2 * (int64_t)sizeof(T));
+}
+
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__restrict__ col,
                                            const float *__restrict__ val, int64_t e0, int64_t e1,
@@ -414,8 +429,7 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
         for (int u = 0; u < U; ++u) {
             // entries past the end of the row point at row 0 (a harmless cached read); their
             // products are skipped below, so non-finite values there cannot leak in
-            x[u] = *(const Raw *)((const char *)p.B + (int64_t)(c[u] < 0 ? 0 : c[u]) * ldb_bytes +
-                                  ld_off);
+            x[u] = *(const Raw *)(narrow_row_ptr<T>(p, c[u] < 0 ? 0 : c[u]) + ld_off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -561,8 +575,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
                     Raw z = {};
                     x[ru][u] = z;
                     if (ok)
-                        x[ru][u] = *(const Raw *)((const char *)p.B + (int64_t)c * ldb_bytes +
-                                                  ld_off);
+                        x[ru][u] = *(const Raw *)(narrow_row_ptr<T>(p, c) + ld_off);
                 }
             }
 #pragma unroll
@@ -807,6 +820,8 @@ int spmm_typed(const gcn_csr_plan *plan, KParams &kp, hipStream_t s)
     const int F = kp.F;
     const bool is64 = plan->rowptr_is64 != 0;
     const bool vec_ok = (F % VECW == 0) && (((uintptr_t)kp.B) % 16 == 0) &&
+                        (((uintptr_t)kp.B2) % 16 == 0) &&
+                        ((kp.ldb2 * (int64_t)sizeof(T)) % 16 == 0) &&
                         (((uintptr_t)kp.C) % 16 == 0) &&
                         ((kp.ldb * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((kp.ldc * (int64_t)sizeof(T)) % 16 == 0);
@@ -973,7 +988,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     if (plan->n_rows < 0 || plan->n_cols < 0 || plan->nnz < 0 || F < 0 || F > INT32_MAX)
         return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: negative size");
     if (plan->n_rows == 0 || F == 0) return 0;
-    if (C == nullptr || (B == nullptr && plan->nnz > 0))
+    if (C == nullptr || (B == nullptr && plan->nnz > 0 && !(ep && ep->b2 && ep->b_split == 0)))
         return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: B or C is NULL");
     if (ldb < F || ldc < F) return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: ldb/ldc smaller than F");
     if (ldb * 4 >= ((int64_t)1 << 32))
@@ -1018,6 +1033,11 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.drop_scale = 1.f / (1.f - drop_p);
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
+    kp.B2 = ep ? ep->b2 : nullptr;
+    kp.ldb2 = ep && ep->b2 ? ep->ldb2 : 0;
+    kp.b_split = (ep && ep->b2) ? (int32_t)std::min<int64_t>(ep->b_split, INT32_MAX) : INT32_MAX;
+    if (ep && ep->b2 && (ep->b_split < 0 || ep->ldb2 < F || ep->ldb2 * 4 >= ((int64_t)1 << 32)))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: bad second block of B");
     kp.bflag = ep ? ep->b_row_nonzero : nullptr;
     kp.bnnz = ep ? ep->b_nnz_rows : nullptr;
     if (kp.bflag == nullptr || kp.bnnz == nullptr) kp.bflag = nullptr, kp.bnnz = nullptr;
@@ -1038,6 +1058,9 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.seed = 0;
     ep.b_row_nonzero = nullptr;
     ep.b_nnz_rows = nullptr;
+    ep.b2 = nullptr;
+    ep.ldb2 = 0;
+    ep.b_split = 0;
     return gcn_spmm_csr_ep(plan, dtype, B, ldb, C, ldc, F, &ep, workspace, workspace_bytes, stream);
 }
 

@@ -19,8 +19,8 @@ same layer (reference pygcn/layers.py:32-38):
     "halo" (default) moves a row only to the ranks whose block references it: at setup every rank
     sends each owner the sorted list of that owner's rows it needs (one grouped P2P round); per
     product the owner packs those rows (index_select) and one grouped isend/irecv round lands them
-    behind the rank's own rows in a compact buffer [n_local + n_halo, F], to which the local
-    column ids were remapped once.  On R-MAT graphs more than half of the rows are referenced by
+    in a halo buffer [n_halo, F]; the local column ids were remapped once to [own rows | halo
+    rows], and the kernels read that two-block operand in place (no copy of the own rows).  On R-MAT graphs more than half of the rows are referenced by
     no remote rank at all (self-loop-only vertices), and xGMI is point-to-point, so sending only
     what is needed, directly owner -> consumer, is the right shape for it.
 
@@ -138,12 +138,13 @@ class HaloExchange:
         self.n_buf = self.n_local + self.n_halo
 
     def exchange(self, local):
-        """[n_local, F] -> [n_local + n_halo, F]: own rows followed by the referenced remote rows."""
+        """[n_local, F] -> the referenced remote rows [n_halo, F].  The rank's own rows are NOT
+        copied: the product reads them in place from `local` and the halo rows from the returned
+        buffer (two-block dense operand, gcn_epilogue.b2)."""
         F = local.shape[1]
-        buf = torch.empty((self.n_buf, F), dtype=local.dtype, device=local.device)
-        buf[:self.n_local].copy_(local)
+        halo = torch.empty((self.n_halo, F), dtype=local.dtype, device=local.device)
         if self.world == 1:
-            return buf
+            return halo
         packed = local.index_select(0, self.send_idx)
         sends, recvs, so = [], [], 0
         for k in range(1, self.world):
@@ -152,10 +153,10 @@ class HaloExchange:
             sends.append((packed[off:off + self.send_counts[s]], s))
         for k in range(1, self.world):
             r = (self.rank - k) % self.world
-            o = self.n_local + self.halo_off[r]
-            recvs.append((buf[o:o + self.recv_counts[r]], r))
+            o = self.halo_off[r]
+            recvs.append((halo[o:o + self.recv_counts[r]], r))
         _p2p_round(sends, recvs, self.group)
-        return buf
+        return halo
 
 
 class ShardedGraph:
@@ -219,13 +220,16 @@ class ShardedGraph:
         if self.timing is not None and local.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
         if self.exchange_mode == "halo":
-            gathered = (self.halo_t if transpose else self.halo).exchange(local)
+            halo = (self.halo_t if transpose else self.halo).exchange(local)
+            # dense operand = [own rows (in place) ; halo rows]
+            out = self._spmm(self.At if transpose else self.A, local, bias=bias, relu=relu,
+                             tag="bwd_local" if transpose else "fwd_local", B2=halo, **kw)
         else:
             gathered = self.all_gather_rows(local)
-        kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
-        out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
-                         tag="bwd_local" if transpose else "fwd_local", **kw)
+            out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
+                             tag="bwd_local" if transpose else "fwd_local", **kw)
         if ev is not None:
             ev[1].record()
             self.timing.append(("bwd" if transpose else "fwd", ev[0], ev[1]))

@@ -27,17 +27,25 @@ def set_timing_records(records):
 
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
-             b_hint=None):
+             b_hint=None, B2=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
     int32 [ceil(n_cols/32)], nnz_rows int32 [1]) device tensors from backward_with_colsum (or
-    row_bitmap()): rows of B whose bit is clear are not gathered (same result, less traffic)."""
+    row_bitmap()): rows of B whose bit is clear are not gathered (same result, less traffic).
+    `B2`: optional second block of the dense operand — the operand is then [B; B2] stacked by rows
+    without being materialised (the sharded path's own rows | halo rows)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
-    if B.dim() != 2 or B.shape[0] != graph.shape[1]:
-        raise RuntimeError(f"size mismatch, adj {graph.shape} x dense {tuple(B.shape)}")
+    n_b = B.shape[0] + (B2.shape[0] if B2 is not None else 0)
+    if B.dim() != 2 or n_b != graph.shape[1]:
+        raise RuntimeError(f"size mismatch, adj {graph.shape} x dense {(n_b,) + tuple(B.shape[1:])}")
+    if B2 is not None:
+        if B2.dim() != 2 or B2.shape[1] != B.shape[1] or B2.dtype != B.dtype or B2.device != B.device:
+            raise RuntimeError("B2 must match B in width, dtype and device")
+        if B2.shape[1] > 0 and B2.stride(1) != 1:
+            B2 = B2.contiguous()
     if B.dtype not in _DTYPES:
         raise RuntimeError(f"spmm_csr supports float32 and bfloat16, got {B.dtype}")
     if B.device != graph.device:
@@ -69,7 +77,10 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
         ep = _native.GcnEpilogue(bias.data_ptr() if bias is not None else None, int(bool(relu)),
                                  float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                  b_hint[0].data_ptr() if b_hint is not None else None,
-                                 b_hint[1].data_ptr() if b_hint is not None else None)
+                                 b_hint[1].data_ptr() if b_hint is not None else None,
+                                 B2.data_ptr() if B2 is not None and B2.numel() else None,
+                                 B2.stride(0) if B2 is not None and B2.numel() else 0,
+                                 B.shape[0] if B2 is not None else 0)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)

@@ -31,9 +31,11 @@ class _CpuGraph:
         self.nnz = int(col.numel())
 
 
-def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd"):
+def _cpu_spmm(graph, B, bias=None, relu=False, out=None, tag="fwd", B2=None):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gcn_oracle
+    if B2 is not None:
+        B = torch.cat([B, B2])
     assert B.shape[0] == graph.shape[1]
     y = gcn_oracle.spmm_csr(graph.rowptr.numpy(), graph.col.numpy(), graph.val.numpy(),
                             B.detach().numpy())
@@ -171,7 +173,7 @@ def _halo_worker(rank, world, port, out_dir):
         h = HaloExchange(col, bounds, rank, world)
         table = torch.arange(n, dtype=torch.float32).view(n, 1) * torch.tensor([[1.0, 10.0]])
         local = table[bounds[rank]:bounds[rank + 1]].contiguous()
-        buf = h.exchange(local)
+        buf = torch.cat([local, h.exchange(local)])
         assert buf.shape == (h.n_buf, 2)
         got = buf[h.col_local.long()]
         assert torch.equal(got, table[col.long()]), (rank, got, table[col.long()])

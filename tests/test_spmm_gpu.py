@@ -618,3 +618,25 @@ def test_row_sparse_operand_hint_changes_nothing_but_traffic(oracle, dev, F, dty
         r = int(torch.nonzero(keep)[0])
         B2[r, 0] = float("inf")
         assert torch.equal(spmm_csr(g, B2).isfinite(), spmm_csr(g, B2, b_hint=(flags, cnt)).isfinite())
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (7, torch.float32),
+                                     (128, torch.bfloat16)])
+def test_two_block_dense_operand(oracle, dev, F, dtype):
+    """[B ; B2] stacked by rows without materialising it (the sharded path's own rows | halo
+    rows): identical to the product with the concatenated operand, on every kernel path."""
+    from pygcn_amd import spmm_csr
+    a = _skewed_csr(oracle, 1800, 2000, 6, seed=F + 3, empties=50, hubs=((5, 900), (6, 30)))
+    g = _graph(a, dev)
+    gen = torch.Generator(device=dev).manual_seed(F)
+    B = torch.randn(2000, F, generator=gen, device=dev).to(dtype)
+    for split in (0, 1, 777, 1999, 2000):
+        own, halo = B[:split], B[split:].clone()
+        got = spmm_csr(g, own, B2=halo)
+        assert torch.equal(got, spmm_csr(g, B)), split
+    wide = torch.randn(2000, 2 * F + 8, generator=gen, device=dev).to(dtype)   # strided blocks
+    got = spmm_csr(g, wide[:1000, :F], B2=wide[1000:, F:2 * F])
+    ref = spmm_csr(g, torch.cat([wide[:1000, :F], wide[1000:, F:2 * F]]).contiguous())
+    assert torch.equal(got, ref)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        spmm_csr(g, B[:100], B2=B[:100])
