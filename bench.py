@@ -36,10 +36,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 CONFIGS = {
-    # name: (nodes, sampled directed edges, feat)
-    "c4": (10_000_000, 100_000_000, 256),   # the configuration the metric is quoted on
-    "c3": (1_000_000, 10_000_000, 256),
-    "tiny": (50_000, 500_000, 256),
+    # name: (nodes, sampled directed edges, feat, dtype)
+    "c4": (10_000_000, 100_000_000, 256, "f32"),   # the configuration the metric is quoted on
+    "c3": (1_000_000, 10_000_000, 256, "f32"),
+    "c5": (50_000_000, 1_000_000_000, 128, "bf16"),  # BASELINE config 5 (fits one GPU: 120 GB)
+    "tiny": (50_000, 500_000, 256, "f32"),
 }
 
 
@@ -52,6 +53,9 @@ def parse():
     ap.add_argument("--nodes", type=int, default=0)
     ap.add_argument("--edges", type=int, default=0)
     ap.add_argument("--feat", type=int, default=0)
+    ap.add_argument("--dtype", default="", choices=["", "f32", "bf16"],
+                    help="storage type of features / activations / parameters (values and "
+                         "accumulation stay fp32); default: the config's")
     ap.add_argument("--dropout", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--spmm-only", action="store_true",
@@ -198,8 +202,10 @@ def main():
     from pygcn_amd.utils import rmat_graph
     _native.lib()
 
-    n, e, feat = CONFIGS[args.config]
-    n, e, feat = args.nodes or n, args.edges or e, args.feat or feat
+    n, e, feat, dt = CONFIGS[args.config]
+    n, e, feat, dt = args.nodes or n, args.edges or e, args.feat or feat, args.dtype or dt
+    tdtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    esize = 2 if dt == "bf16" else 4
 
     # ---------------------------------------------------------------- inputs (HBM resident)
     t0 = time.perf_counter()
@@ -215,10 +221,10 @@ def main():
         graph = CSRGraph(rowptr, col, val, (n, n), **kw)
         graph.plan()
         graph.t().plan()
-        x = torch.randn(n, feat, generator=gen, device=dev)
+        x = torch.randn(n, feat, generator=gen, device=dev).to(tdtype)
         labels = torch.randint(0, feat, (n,), generator=torch.Generator(device=dev).manual_seed(45),
                                device=dev)
-        model = GCN(feat, feat, feat, dropout=args.dropout).to(dev)
+        model = GCN(feat, feat, feat, dropout=args.dropout).to(dev).to(tdtype)
         adj = graph
         n_local, nnz_local = n, nnz
         fwd_model = model
@@ -229,11 +235,11 @@ def main():
         del rowptr, col, val
         n_local, nnz_local = adj.n_local, adj.nnz_local
         gen.manual_seed(44 + rank)
-        x = torch.randn(n_local, feat, generator=gen, device=dev)
+        x = torch.randn(n_local, feat, generator=gen, device=dev).to(tdtype)
         labels = torch.randint(0, feat, (n_local,), device=dev,
                                generator=torch.Generator(device=dev).manual_seed(45 + rank))
         torch.manual_seed(42)
-        model = GCN(feat, feat, feat, dropout=args.dropout).to(dev)
+        model = GCN(feat, feat, feat, dropout=args.dropout).to(dev).to(tdtype)
         fwd_model = ShardedGCN(model, adj)
     opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
     # upstream epoch: loss on the labelled training nodes only (train.py:140-157 comments,
@@ -251,8 +257,8 @@ def main():
         model.train()
         opt.zero_grad(set_to_none=True)
         out = fwd_model(x, adj)
-        loss = F.nll_loss(out[idx_train], labels[idx_train]) if world == 1 else \
-            fwd_model.nll_loss(out, labels, idx_train)
+        loss = F.nll_loss(out[idx_train].float(), labels[idx_train]) if world == 1 else \
+            fwd_model.nll_loss(out.float(), labels, idx_train)
         loss.backward()
         if world > 1:
             fwd_model.allreduce_grads()
@@ -302,12 +308,12 @@ def main():
         gedges = nnz_total / (t_fwd * 1e-3) / 1e9
         rp_bytes = 4 if nnz < 2 ** 31 - 1 else 8
         # roofline of the dominant kernel (forward SpMM launch) on THIS rank's shard
-        alg = algorithmic_bytes(nnz_local, n_local, feat, 4, rp_bytes)
+        alg = algorithmic_bytes(nnz_local, n_local, feat, esize, rp_bytes)
         kernel_ms = float(np.mean(local_fwd_ms)) if world > 1 else float(np.mean(fwd_ms))
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and dt == "f32":
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
@@ -319,7 +325,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             **({"rehearsal": "one GPU shared by all ranks, gloo staged through the host: "
                              "code-path check only, not a measurement"} if args.rehearsal else {}),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dt, "data": "synthetic",
             "config": {"workload": f"{args.config}: R-MAT(0.57,0.19,0.19,0.05) {n_total} nodes / "
                                    f"{e} sampled edges -> nnz {nnz_total} (dedupe + I, "
                                    f"row-normalized), feat_dim {feat}, 2-layer GCN "
@@ -344,7 +350,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic,
-                         "kernel": "spmm_wide_kernel<float,4> (forward gcn_spmm_csr launch)",
+                         "kernel": ("spmm_wide_kernel<float,4>" if dt == "f32" and feat > 128 else
+                                    "spmm_narrow_kernel") + " (forward gcn_spmm_csr launch)",
                          "algorithmic_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:
