@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 5
+#define GCN_ABI_VERSION 6
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -170,18 +170,19 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
                               int64_t n_elems, float scale, void *stream);
 
 /*
- * The same backward pass for fp32 [n_rows, F] row-major tensors, producing in the same sweep the
+ * The same backward pass for fp32 or bf16 [n_rows, F] row-major tensors (`dtype`; colsum is always
+ * fp32 and, for bf16, sums the rounded values that were stored), producing in the same sweep the
  * column sums of its result: colsum[f] = sum_rows grad_pre[row, f] — the bias gradient of
  * `output + self.bias` (pygcn/layers.py:35-36).  `out == NULL` skips the masking (plain column
  * sums of grad_out; grad_pre is then ignored).  Deterministic (per-block partial rows added in
- * block order, no float atomics).  F must be a multiple of 4 with F/4 dividing 256
- * (4, 8, ..., 256, 512, 1024); scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F).
- * Optional outputs (both or neither; F <= 256): bit r of row_bits[ceil(n_rows/32)] is set where
+ * block order, no float atomics).  F must be a multiple of the 16-byte lane width v (4 fp32 / 8
+ * bf16) with F/v dividing 256; scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F, dtype).
+ * Optional outputs (both or neither; F/v <= 64): bit r of row_bits[ceil(n_rows/32)] is set where
  * row r of the result has a non-zero element, *nnz_rows = how many — the B-operand hint of
  * gcn_epilogue.
  */
-size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F);
-int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
+size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F, int dtype);
+int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
                                      uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
                                      size_t workspace_bytes, void *stream);

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 5
+GCN_ABI_VERSION = 6
 GCN_DEFAULT_ITEM_COST = 64
 GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
@@ -112,9 +112,10 @@ def lib():
     L.gcn_row_normalize_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int64, ctypes.c_void_p]
     L.gcn_bwd_colsum_workspace_bytes.restype = ctypes.c_size_t
-    L.gcn_bwd_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.gcn_bwd_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
     L.gcn_relu_dropout_backward_colsum.restype = ctypes.c_int
-    L.gcn_relu_dropout_backward_colsum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+    L.gcn_relu_dropout_backward_colsum.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                    ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

@@ -660,39 +660,49 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T *__restri
 // [F]; a second tiny kernel adds the partial rows in block order (deterministic, no atomics).
 // MASK = false gives a plain column sum (layer without a fused ReLU).
 // ------------------------------------------------------------------------------------------
-template <bool MASK>
-__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict__ grad_out,
-                                                         const float *__restrict__ out,
-                                                         float *__restrict__ grad_pre,
+template <typename T, int VEC, bool MASK>
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ grad_out,
+                                                         const T *__restrict__ out,
+                                                         T *__restrict__ grad_pre,
                                                          float *__restrict__ partial, int64_t n_rows,
                                                          int F, float scale, int rows_per_block,
                                                          uint8_t *__restrict__ rowflag,
                                                          int32_t *__restrict__ nnz_rows)
 {
-    __shared__ float red[256 * 4];
-    const int CG = F >> 2, RL = 256 / CG;         // column groups, row lanes
+    typedef typename Elem<T, VEC>::Raw Raw;
+    __shared__ float red[256 * VEC];
+    const int CG = F / VEC, RL = 256 / CG;         // column groups (16 B each), row lanes
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(r0 + (int64_t)rows_per_block, n_rows);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     int nz_count = 0;
     for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const int64_t off = r * F + 4 * cg;
-        f32x4 g = *(const f32x4 *)(grad_out + off);
+        const int64_t off = r * F + VEC * cg;
+        float g[VEC];
+        Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
         if (MASK) {
-            const f32x4 o = *(const f32x4 *)(out + off);
-            g.x = o.x > 0.f ? g.x * scale : 0.f;
-            g.y = o.y > 0.f ? g.y * scale : 0.f;
-            g.z = o.z > 0.f ? g.z * scale : 0.f;
-            g.w = o.w > 0.f ? g.w * scale : 0.f;
-            *(f32x4 *)(grad_pre + off) = g;
+            float o[VEC];
+            Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] * scale : 0.f;
+            const Raw packed = Elem<T, VEC>::pack(g);
+            *(Raw *)(grad_pre + off) = packed;
+            Elem<T, VEC>::unpack(packed, g);   // sums and flags follow the STORED (rounded) values
         }
-        acc += g;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            acc[i] += g[i];
+            any |= (g[i] != 0.f);
+        }
         if (rowflag != nullptr) {
             // a row lives in CG <= 64 consecutive lanes of one wave (all active or all inactive
             // together): its non-zero flag is a slice of the wave's ballot over the active lanes;
             // the row's first lane writes the byte
-            const unsigned long long b = __ballot(g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f);
+            const unsigned long long b = __ballot(any);
             const int lane = threadIdx.x & 63;
             if (cg == 0) {
                 const unsigned long long m = CG >= 64 ? ~0ull : (((1ull << CG) - 1) << (lane & ~(CG - 1)));
@@ -708,11 +718,15 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const float *__restrict
         for (int off = 32; off > 0; off >>= 1) nz_count += __shfl_xor(nz_count, off, 64);
         if ((threadIdx.x & 63) == 0 && nz_count) atomicAdd(nnz_rows, nz_count);
     }
-    *(f32x4 *)(red + threadIdx.x * 4) = acc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[threadIdx.x * VEC + i] = acc[i];
     __syncthreads();
     if (rl == 0) {
-        for (int k = 1; k < RL; ++k) acc += *(const f32x4 *)(red + (k * CG + cg) * 4);   // fixed order
-        *(f32x4 *)(partial + (int64_t)blockIdx.x * F + 4 * cg) = acc;
+        for (int k = 1; k < RL; ++k)   // fixed order
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] += red[(k * CG + cg) * VEC + i];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) partial[(int64_t)blockIdx.x * F + VEC * cg + i] = acc[i];
     }
 }
 
@@ -1103,30 +1117,36 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
     return 0;
 }
 
-static bool colsum_shape_ok(int64_t F)
+static bool colsum_shape_ok(int64_t F, int dtype)
 {
-    return F >= 4 && F <= 1024 && (F % 4) == 0 && (256 % (F / 4)) == 0;
+    const int64_t v = dtype == GCN_DTYPE_BF16 ? 8 : 4;   // elements per 16-byte lane
+    return F >= v && F <= 256 * v && (F % v) == 0 && (256 % (F / v)) == 0;
 }
 
-size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F)
+size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F, int dtype)
 {
-    if (n_rows <= 0 || !colsum_shape_ok(F)) return 0;
+    if (n_rows <= 0 || (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16) ||
+        !colsum_shape_ok(F, dtype))
+        return 0;
     const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
     // partial column sums + one byte per row (staging for the row bitmap)
     return (size_t)blocks * (size_t)F * sizeof(float) + (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
-int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, float *grad_pre,
+int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
                                      uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
                                      size_t workspace_bytes, void *stream)
 {
+    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: unknown dtype");
     if ((row_bits == nullptr) != (nnz_rows == nullptr))
         return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: row_bits and nnz_rows go together");
-    if (row_bits != nullptr && F > 256) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
-    if (n_rows < 0 || !colsum_shape_ok(F))
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of 4 with "
-                                  "F/4 dividing 256");
+    const int64_t vec = dtype == GCN_DTYPE_BF16 ? 8 : 4;
+    if (row_bits != nullptr && F / vec > 64) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
+    if (n_rows < 0 || !colsum_shape_ok(F, dtype))
+        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of the "
+                                  "16-byte lane width with F/width dividing 256");
     if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))
         return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -1138,7 +1158,7 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
         hipError_t e = hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), s);
         return e == hipSuccess ? 0 : fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
     }
-    const size_t need = gcn_bwd_colsum_workspace_bytes(n_rows, F);
+    const size_t need = gcn_bwd_colsum_workspace_bytes(n_rows, F, dtype);
     if (workspace == nullptr || workspace_bytes < need)
         return fail(GCN_E_WORKSPACE, "gcn_relu_dropout_backward_colsum: workspace too small");
     if (((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)grad_pre | (uintptr_t)workspace) % 16 != 0)
@@ -1147,14 +1167,27 @@ int gcn_relu_dropout_backward_colsum(const float *grad_out, const float *out, fl
     const int rows_per_block = (int)((n_rows + blocks - 1) / blocks);
     uint8_t *row_nonzero = row_bits ? (uint8_t *)workspace + (size_t)blocks * (size_t)F * sizeof(float)
                                     : nullptr;
-    if (out != nullptr)
-        hipLaunchKernelGGL(bwd_colsum_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
-                           out, grad_pre, (float *)workspace, n_rows, (int)F, scale, rows_per_block,
-                           row_nonzero, nnz_rows);
-    else
-        hipLaunchKernelGGL(bwd_colsum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out,
-                           (const float *)nullptr, (float *)nullptr, (float *)workspace, n_rows, (int)F,
-                           scale, rows_per_block, row_nonzero, nnz_rows);
+    const dim3 grid((unsigned)blocks), block(256);
+    float *part = (float *)workspace;
+    if (dtype == GCN_DTYPE_F32) {
+        if (out != nullptr)
+            hipLaunchKernelGGL((bwd_colsum_kernel<float, 4, true>), grid, block, 0, s,
+                               (const float *)grad_out, (const float *)out, (float *)grad_pre, part,
+                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+        else
+            hipLaunchKernelGGL((bwd_colsum_kernel<float, 4, false>), grid, block, 0, s,
+                               (const float *)grad_out, (const float *)nullptr, (float *)nullptr, part,
+                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+    } else {
+        if (out != nullptr)
+            hipLaunchKernelGGL((bwd_colsum_kernel<bf16_t, 8, true>), grid, block, 0, s,
+                               (const bf16_t *)grad_out, (const bf16_t *)out, (bf16_t *)grad_pre, part,
+                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+        else
+            hipLaunchKernelGGL((bwd_colsum_kernel<bf16_t, 8, false>), grid, block, 0, s,
+                               (const bf16_t *)grad_out, (const bf16_t *)nullptr, (bf16_t *)nullptr,
+                               part, n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+    }
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 31) / 32)), dim3(1024), 0, s,
                        (const float *)workspace, colsum, (int)blocks, (int)F);
     if (row_bits != nullptr)

@@ -116,29 +116,30 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
     relu_dropout_backward + torch's sum)."""
     _require_cuda(grad_out, "grad_out")
     L = _native.lib()
-    if (grad_out.dtype != torch.float32 or grad_out.dim() != 2
+    if (grad_out.dtype not in _DTYPES or grad_out.dim() != 2
             or not grad_out.is_contiguous() or grad_out.shape[0] == 0
-            or L.gcn_bwd_colsum_workspace_bytes(grad_out.shape[0], grad_out.shape[1]) == 0
-            or (out is not None and (out.dtype != torch.float32 or not out.is_contiguous()
+            or L.gcn_bwd_colsum_workspace_bytes(grad_out.shape[0], grad_out.shape[1],
+                                                _DTYPES[grad_out.dtype]) == 0
+            or (out is not None and (out.dtype != grad_out.dtype or not out.is_contiguous()
                                      or out.shape != grad_out.shape))):
         return None
     n, F = grad_out.shape
     grad_pre = torch.empty_like(grad_out) if out is not None else grad_out
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
     hint = None
-    if F <= 256:   # a row then lives inside one wavefront of the kernel: flags come for free
+    if F <= (256 if grad_out.dtype == torch.float32 else 512):   # a row lives inside one wavefront
         hint = (torch.empty((n + 31) // 32, dtype=torch.int32, device=grad_out.device),   # bitmap
                 torch.empty(1, dtype=torch.int32, device=grad_out.device))
-    ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F)
+    ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F, _DTYPES[grad_out.dtype])
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
         rc = L.gcn_relu_dropout_backward_colsum(
-            grad_out.data_ptr(), out.data_ptr() if out is not None else None,
+            _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr() if out is not None else None,
             grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
             hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None,
             ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_relu_dropout_backward_colsum")
-    return grad_pre, colsum, hint
+    return grad_pre, colsum.to(grad_out.dtype), hint
 
 
 def row_bitmap(B):

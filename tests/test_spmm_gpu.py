@@ -587,7 +587,28 @@ def test_backward_with_colsum_matches_torch(dev, F):
         assert float((cq.double() - go.double().sum(0)).abs().max()) <= \
             1e-5 * float(go.abs().sum(0).max()) + 1e-6
     assert backward_with_colsum(torch.randn(10, 7, device=dev)) is None
-    assert backward_with_colsum(torch.randn(10, 256, device=dev).bfloat16()) is None
+    assert backward_with_colsum(torch.randn(10, 12, device=dev).bfloat16()) is None   # 12 % 8 != 0
+
+
+@pytest.mark.parametrize("F", [8, 128, 512])
+def test_backward_with_colsum_bf16(dev, F):
+    """bf16 storage (config C5): same pass on 8-element lanes; sums and flags follow the stored
+    (rounded) values."""
+    from pygcn_amd.spmm import backward_with_colsum, row_bitmap
+    for n in (5, 1000, 40001):
+        gen = torch.Generator(device=dev).manual_seed(n + F)
+        go = torch.randn(n, F, generator=gen, device=dev).bfloat16()
+        out = torch.randn(n, F, generator=gen, device=dev).bfloat16()
+        go[1::4] = 0
+        gp, cs, hint = backward_with_colsum(go, out, 2.0)
+        ref = torch.where(out.float() > 0, go.float() * 2.0, torch.zeros(n, F, device=dev)).bfloat16()
+        assert gp.dtype == torch.bfloat16 and torch.equal(gp, ref)
+        ref_cs = ref.double().sum(0)
+        tol = 2.0 ** -7 * float(ref.float().abs().sum(0).max()) + 1e-3
+        assert float((cs.double() - ref_cs).abs().max()) <= tol
+        bits, cnt = hint
+        rb, rc = row_bitmap(ref)
+        assert torch.equal(bits, rb) and int(cnt) == int(rc)
 
 
 @pytest.mark.parametrize("F,dtype", [(256, torch.float32), (512, torch.float32), (64, torch.float32),
