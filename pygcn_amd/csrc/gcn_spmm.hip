@@ -412,7 +412,54 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
 {
     typedef typename Elem<T, VEC>::Raw Raw;
     constexpr int G = kWave / LPR;
-    const int64_t ldb_bytes = p.ldb * (int64_t)sizeof(T);
+    if (flags) {
+        // Row-sparse dense operand: per 64-entry tile probe the row bitmap once per lane, move the
+        // surviving entries to the front of the wave (a full lane permutation: survivors keep
+        // their order in [0, nv), the rest go behind), then split ONLY the survivors over the G
+        // lane groups.  Skipped entries cost neither a bitmap-dependent stall per entry nor a load.
+        const int lane = (int)(threadIdx.x & (kWave - 1));
+        for (int64_t t = e0; t < e1; t += kWave) {
+            const int cnt = (int)min((int64_t)kWave, e1 - t);
+            int c = 0;
+            float a = 0.f;
+            bool keep = false;
+            if (lane < cnt) {
+                c = col[t + lane];
+                a = val[t + lane];
+                keep = row_bit(p.bflag, c);
+            }
+            const unsigned long long m = __ballot(keep);
+            const int nv = __builtin_popcountll(m);
+            if (nv == 0) continue;   // wave-uniform
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const int dest = keep ? below : nv + (lane - below);   // a permutation of 0..63
+            const int cc = __builtin_amdgcn_ds_permute(dest << 2, c);
+            const float aa = __int_as_float(__builtin_amdgcn_ds_permute(dest << 2, __float_as_int(a)));
+            for (int k = 0; k < nv; k += G * U) {   // uniform trip count
+                Raw x[U];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = k + u * G + g;
+                    const bool ok = idx < nv;
+                    const int ck = __shfl(cc, idx & (kWave - 1), kWave);
+                    const float ak = __shfl(aa, idx & (kWave - 1), kWave);
+                    w[u] = ok ? ak : 0.f;
+                    Raw z = {};
+                    x[u] = z;
+                    if (ok) x[u] = *(const Raw *)(narrow_row_ptr<T>(p, ck) + ld_off);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {   // unloaded slots hold zeros with weight 0: exact
+                    float xf[VEC];
+                    Elem<T, VEC>::unpack(x[u], xf);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = fmaf(w[u], xf[i], acc[i]);
+                }
+            }
+        }
+    } else
     for (int64_t e = e0; e < e1; e += (int64_t)G * U) {   // uniform trip count
         int c[U];
         float a[U];
@@ -423,18 +470,17 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
             const bool ok = ee < e1;
             c[u] = ok ? col[ee] : 0;
             a[u] = ok ? val[ee] : 0.f;
-            if (flags && ok && !row_bit(p.bflag, c[u])) a[u] = 0.f, c[u] = -1;   // all-zero row: skip
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             // entries past the end of the row point at row 0 (a harmless cached read); their
             // products are skipped below, so non-finite values there cannot leak in
-            x[u] = *(const Raw *)(narrow_row_ptr<T>(p, c[u] < 0 ? 0 : c[u]) + ld_off);
+            x[u] = *(const Raw *)(narrow_row_ptr<T>(p, c[u]) + ld_off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t ee = e + (int64_t)u * G + g;
-            if (ee < e1 && c[u] >= 0) {
+            if (ee < e1) {
                 float xf[VEC];
                 Elem<T, VEC>::unpack(x[u], xf);
 #pragma unroll
