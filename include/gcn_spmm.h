@@ -141,8 +141,9 @@ typedef struct gcn_epilogue {
     /* Optional hint about the dense operand B (both NULL = none): bit c of the bitmap
      * b_row_nonzero[ceil(n_cols/32)] is clear for rows of B that are entirely zero, *b_nnz_rows
      * counts the rows whose bit is set.  Such rows are
-     * not gathered (their products are zero anyway, so the result is unchanged); the hint is
-     * ignored on the device when 3/4 or more of the rows are non-zero.  Produced for free by
+     * not gathered (their products are zero anyway, so the result is unchanged up to summation
+     * order); the hint is ignored on the device when it cannot pay (3/4 or more of the rows
+     * non-zero for rows of >= 528 bytes, 1/8 or more for narrower rows).  Produced for free by
      * gcn_relu_dropout_backward_colsum — the gradients of a semi-supervised loss
      * (`nll_loss(output[idx_train], ...)`, pygcn/train.py) are non-zero on few rows. */
     const uint32_t *b_row_nonzero;

@@ -630,7 +630,11 @@ def test_row_sparse_operand_hint_changes_nothing_but_traffic(oracle, dev, F, dty
     flags, cnt = row_bitmap(B)
     plain = spmm_csr(g, B)
     hinted = spmm_csr(g, B, b_hint=(flags, cnt))
-    assert torch.equal(plain, hinted)
+    if F >= 256 and dtype == torch.float32:
+        assert torch.equal(plain, hinted)     # wide kernel: same summation order, bitwise equal
+    else:                                     # narrow kernel: survivors are re-dealt to the lane
+        assert_normwise(hinted.float().cpu(), plain.float().cpu().numpy(),   # groups: rounding order
+                        2.0 ** -8 if dtype == torch.bfloat16 else 1e-6, "hinted vs plain")
     ref = a.matmul(B.float().cpu().numpy())
     assert_normwise(hinted.float().cpu(), ref, 2.0 ** -8 if dtype == torch.bfloat16 else TOL, "hinted")
     # non-finite values in a flagged-NONZERO row still propagate
