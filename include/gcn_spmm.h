@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 6
+#define GCN_ABI_VERSION 7
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -155,6 +155,11 @@ typedef struct gcn_epilogue {
     const void *b2;
     int64_t ldb2;
     int64_t b_split;
+    /* Optional OUTPUT (NULL = none): byte flags [n_rows], zeroed by the caller; c_row_nonzero[r]
+     * is set to 1 where row r of the stored result has a non-zero element.  Lets the consumer of a
+     * row-sparse product (the weight / input gradient GEMMs behind A^T · grad) skip the zero rows
+     * without another pass over the result. */
+    uint8_t *c_row_nonzero;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

@@ -85,6 +85,7 @@ struct KParams {
     const uint32_t *bflag;   // optional bitmap [ceil(n_cols/32)]: bit c clear = row c of B is all zero
     const int32_t *bnnz;     // optional device scalar: number of non-zero rows of B
     int32_t n_cols;
+    uint8_t *cflag;          // optional output [n_rows], pre-zeroed: 1 = stored row has a non-zero
 };
 
 // ------------------------------------------------------------------------------------------
@@ -231,6 +232,12 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
     if (act) {
         T *dst = (T *)p.C + row * p.ldc + f;
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
+    }
+    if (p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
+        bool nz = false;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) nz |= (o[i] != 0.f);
+        if (act && nz) p.cflag[row] = 1;
     }
 }
 
@@ -1104,6 +1111,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.bflag = ep ? ep->b_row_nonzero : nullptr;
     kp.bnnz = ep ? ep->b_nnz_rows : nullptr;
     if (kp.bflag == nullptr || kp.bnnz == nullptr) kp.bflag = nullptr, kp.bnnz = nullptr;
+    kp.cflag = ep ? ep->c_row_nonzero : nullptr;
     kp.n_cols = (int32_t)std::min<int64_t>(plan->n_cols, INT32_MAX);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GCN_DTYPE_F32) return spmm_typed<float, 4>(plan, kp, s);
@@ -1121,6 +1129,7 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.seed = 0;
     ep.b_row_nonzero = nullptr;
     ep.b_nnz_rows = nullptr;
+    ep.c_row_nonzero = nullptr;
     ep.b2 = nullptr;
     ep.ldb2 = 0;
     ep.b_split = 0;

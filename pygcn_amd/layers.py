@@ -20,7 +20,8 @@ from torch.nn.parameter import Parameter
 if not __package__:   # imported flat, the reference's convention (`from layers import ...`)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
-from pygcn_amd.spmm import DenseMMFunction, SpMMFunction, next_dropout_seed  # noqa: E402
+from pygcn_amd.spmm import (DenseMMFunction, GraphConvFunction, SpMMFunction,  # noqa: E402
+                            next_dropout_seed)
 from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
@@ -71,8 +72,8 @@ class GraphConvolution(Module):
             output = output + self.bias if self.bias is not None else output
             output = torch.relu(output) if relu else output
             return torch.nn.functional.dropout(output, dropout, True) if dropout > 0.0 else output
-        support = DenseMMFunction.apply(input, self.weight)
-        return SpMMFunction.apply(as_graph(adj), support, self.bias, relu, dropout, seed)
+        return GraphConvFunction.apply(input, self.weight, self.bias, as_graph(adj), relu, dropout,
+                                       seed)
 
     def _forward_batched(self, input, adj, relu):
         """k samples over the same graph in ONE sparse product.  The fork runs

@@ -27,14 +27,16 @@ def set_timing_records(records):
 
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
-             b_hint=None, B2=None):
+             b_hint=None, B2=None, c_flags=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
     int32 [ceil(n_cols/32)], nnz_rows int32 [1]) device tensors from backward_with_colsum (or
     row_bitmap()): rows of B whose bit is clear are not gathered (same result, less traffic).
     `B2`: optional second block of the dense operand — the operand is then [B; B2] stacked by rows
-    without being materialised (the sharded path's own rows | halo rows)."""
+    without being materialised (the sharded path's own rows | halo rows).
+    `c_flags`: optional uint8 [n_rows] tensor of ZEROS; the kernel sets c_flags[r] = 1 where the
+    stored row r has a non-zero element (gcn_epilogue.c_row_nonzero)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -57,6 +59,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
         out = torch.empty((n_rows, F), dtype=B.dtype, device=B.device)
     elif out.shape != (n_rows, F) or out.dtype != B.dtype or out.stride(1) != 1:
         raise RuntimeError("spmm_csr: bad `out`")
+    if c_flags is not None and (c_flags.dtype != torch.uint8 or c_flags.numel() != n_rows
+                                or not c_flags.is_contiguous() or c_flags.device != B.device):
+        raise RuntimeError("spmm_csr: c_flags must be a contiguous uint8 [n_rows] device tensor")
     if n_rows == 0 or F == 0:
         return out
     if bias is not None:
@@ -80,7 +85,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  b_hint[1].data_ptr() if b_hint is not None else None,
                                  B2.data_ptr() if B2 is not None and B2.numel() else None,
                                  B2.stride(0) if B2 is not None and B2.numel() else 0,
-                                 B.shape[0] if B2 is not None else 0)
+                                 B.shape[0] if B2 is not None else 0,
+                                 c_flags.data_ptr() if c_flags is not None else None)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -231,6 +237,54 @@ def gemm_xw256(X, W):
     return Y
 
 
+def _dense_forward(input, weight):
+    out = gemm_xw256(input, weight)
+    return out if out is not None else torch.mm(input, weight)
+
+
+K_SPLIT = 128          # slabs of the weight-gradient reduction
+MIN_ROWS = 1 << 17     # below this the plain GEMMs are launch-bound anyway
+
+
+def _weight_grad(input, grad):
+    """inputᵀ · grad with the reduction over the graph's vertices cut into K_SPLIT slabs."""
+    n, b = input.shape[0], K_SPLIT
+    if n >= MIN_ROWS and input.is_contiguous() and grad.is_contiguous():
+        m = n // b * b
+        grad_w = torch.bmm(input[:m].view(b, m // b, -1).transpose(1, 2),
+                           grad[:m].view(b, m // b, -1)).sum(0)
+        if m < n:
+            grad_w = grad_w + torch.mm(input[m:].t(), grad[m:])
+        return grad_w
+    return torch.mm(input.t(), grad)
+
+
+def _dense_grads(input, weight, grad, need_in, need_w, rows=None):
+    """(grad_input, grad_weight) of `input @ weight`.  `rows` (int64 indices, sorted) names the
+    only rows of `grad` that are non-zero: both GEMMs then run on those rows alone — zero rows
+    add nothing to inputᵀ·grad and give zero rows of grad·weightᵀ."""
+    grad_in = grad_w = None
+    if rows is not None:
+        grad = grad.index_select(0, rows)
+        if need_w:
+            grad_w = _weight_grad(input.index_select(0, rows), grad)
+        if need_in:
+            part = gemm_xw256(grad, weight.t().contiguous())
+            if part is None:
+                part = torch.mm(grad, weight.t())
+            grad_in = torch.zeros((input.shape[0], weight.shape[0]), dtype=part.dtype,
+                                  device=part.device)
+            grad_in.index_copy_(0, rows, part)
+        return grad_in, grad_w
+    if need_in:
+        grad_in = gemm_xw256(grad, weight.t().contiguous())
+        if grad_in is None:
+            grad_in = torch.mm(grad, weight.t())
+    if need_w:
+        grad_w = _weight_grad(input, grad)
+    return grad_in, grad_w
+
+
 class DenseMMFunction(torch.autograd.Function):
     """`torch.mm(input, weight)` (reference pygcn/layers.py:33) with a K-split weight gradient.
 
@@ -243,34 +297,83 @@ class DenseMMFunction(torch.autograd.Function):
     Forward and grad_input use the hand-written MFMA kernel when the layer is 256 -> 256 fp32
     (gemm_xw256: 8.0 ms vs hipBLASLt 9.95 ms at N = 10⁷), torch.mm otherwise."""
 
-    K_SPLIT = 128
-    MIN_ROWS = 1 << 17
+    K_SPLIT = K_SPLIT
+    MIN_ROWS = MIN_ROWS
 
     @staticmethod
     def forward(ctx, input, weight):
         ctx.save_for_backward(input, weight)
-        out = gemm_xw256(input, weight)
-        return out if out is not None else torch.mm(input, weight)
+        return _dense_forward(input, weight)
 
     @staticmethod
     def backward(ctx, grad):
         input, weight = ctx.saved_tensors
-        grad_in = grad_w = None
-        if ctx.needs_input_grad[0]:
-            grad_in = gemm_xw256(grad, weight.t().contiguous())
-            if grad_in is None:
-                grad_in = torch.mm(grad, weight.t())
-        if ctx.needs_input_grad[1]:
-            n, b = input.shape[0], DenseMMFunction.K_SPLIT
-            if n >= DenseMMFunction.MIN_ROWS and input.is_contiguous() and grad.is_contiguous():
-                m = n // b * b
-                grad_w = torch.bmm(input[:m].view(b, m // b, -1).transpose(1, 2),
-                                   grad[:m].view(b, m // b, -1)).sum(0)
-                if m < n:
-                    grad_w = grad_w + torch.mm(input[m:].t(), grad[m:])
-            else:
-                grad_w = torch.mm(input.t(), grad)
-        return grad_in, grad_w
+        return _dense_grads(input, weight, grad, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+_row_compaction = True
+
+
+def set_row_compaction(enabled):
+    """Row compaction of the layer's gradient GEMMs reads two device counters on the host (two
+    stream synchronisations per layer backward, only for graphs of >= MIN_ROWS vertices).  Switch
+    it off to keep the backward pass free of synchronisation (it is skipped by itself while the
+    stream is being captured into a hipGraph)."""
+    global _row_compaction
+    _row_compaction = bool(enabled)
+
+
+class GraphConvFunction(torch.autograd.Function):
+    """The whole layer — `torch.mm(input, weight)`, `torch.spmm(adj, support)`, `+ bias`
+    (reference pygcn/layers.py:33-36) and the optional fused ReLU / dropout — as ONE autograd
+    node, so that what the backward pass learns about the sparsity of its tensors can be used by
+    the next stage instead of being re-discovered:
+
+        grad_pre  = mask(grad_out)                 -> row bitmap + count   (one HIP pass)
+        grad_sup  = Aᵀ · grad_pre   (skips zero rows of grad_pre) -> byte flags of ITS non-zero rows
+        grad_W    = inputᵀ · grad_sup,  grad_input = grad_sup · Wᵀ   on the non-zero rows only
+
+    With a loss on few labelled vertices (`nll_loss(output[idx_train], …)`, pygcn/train.py:153)
+    grad_out of the last layer is non-zero on |idx_train| rows and grad_sup on their neighbourhood:
+    5 % and 16 % of the rows at bench config C4."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, graph, relu=False, dropout_p=0.0, seed=0):
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
+        ctx.graph = graph
+        ctx.relu = bool(relu)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        support = _dense_forward(input, weight)
+        out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
+        if relu:
+            ctx.save_for_backward(input, weight, out)
+        else:
+            ctx.save_for_backward(input, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        input, weight = ctx.saved_tensors[:2]
+        out = ctx.saved_tensors[2] if ctx.relu else None
+        need_in, need_w, need_b = ctx.needs_input_grad[:3]
+        grad_pre, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale, need_b)
+        if not (need_in or need_w):
+            return None, None, grad_bias, None, None, None, None
+        graph_t = ctx.graph.t()
+        n = graph_t.shape[0]
+        c_flags = rows = None
+        if (hint is not None and _row_compaction and n >= MIN_ROWS
+                and not torch.cuda.is_current_stream_capturing()
+                and int(hint[1].item()) * 8 < grad_pre.shape[0]):
+            c_flags = torch.zeros(n, dtype=torch.uint8, device=grad_pre.device)
+        grad_sup = spmm_csr(graph_t, grad_pre.contiguous(), tag="bwd", b_hint=hint, c_flags=c_flags)
+        if c_flags is not None:
+            rows = torch.nonzero(c_flags).squeeze(1)
+            if rows.numel() * 3 >= n:
+                rows = None
+        grad_in, grad_w = _dense_grads(input, weight, grad_sup, need_in, need_w, rows)
+        return grad_in, grad_w, grad_bias, None, None, None, None
 
 
 def spmm(adj, dense, bias=None):

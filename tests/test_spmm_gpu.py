@@ -665,3 +665,86 @@ def test_two_block_dense_operand(oracle, dev, F, dtype):
     assert torch.equal(got, ref)
     with pytest.raises(RuntimeError, match="size mismatch"):
         spmm_csr(g, B[:100], B2=B[:100])
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (600, torch.float32), (64, torch.float32),
+                                     (16, torch.float32), (7, torch.float32), (128, torch.bfloat16),
+                                     (512, torch.bfloat16)])
+def test_output_row_flags(oracle, dev, F, dtype):
+    """gcn_epilogue.c_row_nonzero: byte r is set exactly where the stored row r has a non-zero
+    element — on the wide, narrow (short / medium rows) and long-row (partial slab + reduce)
+    paths, with and without the operand hint, and through a ReLU that zeroes whole rows."""
+    from pygcn_amd import spmm_csr
+    from pygcn_amd.spmm import row_bitmap
+    a = _skewed_csr(oracle, 2500, 2200, 6, seed=F + 11, empties=100,
+                    hubs=((3, 1200), (900, 300), (901, 40)))
+    g = _graph(a, dev)
+    gen = torch.Generator(device=dev).manual_seed(F)
+    B = torch.randn(2200, F, generator=gen, device=dev)
+    keep = torch.rand(2200, generator=gen, device=dev) < 0.03
+    keep[5] = True
+    B = (B * keep[:, None]).to(dtype)
+    for hint in (None, row_bitmap(B)):
+        flags = torch.zeros(2500, dtype=torch.uint8, device=dev)
+        out = spmm_csr(g, B, b_hint=hint, c_flags=flags)
+        expect = (out != 0).any(1)
+        assert torch.equal(flags.bool(), expect)
+        assert 0 < int(expect.sum()) < 2500                   # the case exercises both outcomes
+        assert torch.equal(out, spmm_csr(g, B, b_hint=hint))  # the flags change nothing else
+    bias = -torch.rand(F, device=dev) * 0.05                  # negative bias + ReLU: whole rows -> 0
+    flags = torch.zeros(2500, dtype=torch.uint8, device=dev)
+    out = spmm_csr(g, B, bias=bias, relu=True, c_flags=flags)
+    assert torch.equal(flags.bool(), (out != 0).any(1))
+    with pytest.raises(RuntimeError, match="c_flags"):
+        spmm_csr(g, B, c_flags=torch.zeros(2499, dtype=torch.uint8, device=dev))
+
+
+def test_layer_backward_row_compaction(oracle, dev):
+    """GraphConvFunction runs the weight / input gradient GEMMs on the non-zero rows of
+    Aᵀ·grad_pre only when the loss touches few vertices.  Same gradients as the uncompacted
+    backward (up to the summation order of grad_W) and as the two-node composition
+    DenseMMFunction + SpMMFunction."""
+    import importlib
+    from pygcn_amd import CSRGraph, GraphConvolution
+    from pygcn_amd.utils import rmat_graph
+    S = importlib.import_module("pygcn_amd.spmm")   # `pygcn_amd.spmm` the attribute is the function
+    n = 1 << 18
+    rowptr, col, val = rmat_graph(n, 4 * n, seed=5, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    assert n >= S.MIN_ROWS
+    torch.manual_seed(0)
+    l1, l2 = GraphConvolution(48, 256).to(dev), GraphConvolution(256, 256).to(dev)
+    x = torch.randn(n, 48, device=dev)
+    idx = torch.randperm(n, device=dev)[: n // 400]
+    tgt = torch.randn(idx.numel(), 256, device=dev)
+
+    def grads(compaction, fused=True):
+        S.set_row_compaction(compaction)
+        try:
+            for p in list(l1.parameters()) + list(l2.parameters()):
+                p.grad = None
+            torch.manual_seed(1)
+            if fused:
+                h = l2(l1(x, g, relu=True, dropout=0.25), g)
+            else:
+                seed = S.next_dropout_seed()
+                h = S.SpMMFunction.apply(g, S.DenseMMFunction.apply(x, l1.weight), l1.bias, True, 0.25, seed)
+                h = S.SpMMFunction.apply(g, S.DenseMMFunction.apply(h, l2.weight), l2.bias)
+            ((h[idx] - tgt) ** 2).sum().backward()
+            return [p.grad.clone() for p in list(l1.parameters()) + list(l2.parameters())]
+        finally:
+            S.set_row_compaction(True)
+
+    calls = []
+    orig = S._dense_grads
+    S._dense_grads = lambda *a, **k: (calls.append(a[5] if len(a) > 5 else k.get("rows")), orig(*a, **k))[1]
+    try:
+        compact = grads(True)
+    finally:
+        S._dense_grads = orig
+    assert any(r is not None and 0 < r.numel() < n // 3 for r in calls), "compaction did not engage"
+    dense = grads(False)
+    two_node = grads(False, fused=False)
+    for c, d, t in zip(compact, dense, two_node):
+        assert torch.equal(d, t)
+        assert_normwise(c.cpu(), d.cpu().numpy(), TOL, "compacted vs dense backward")
