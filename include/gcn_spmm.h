@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 7
+#define GCN_ABI_VERSION 8
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -160,6 +160,12 @@ typedef struct gcn_epilogue {
      * row-sparse product (the weight / input gradient GEMMs behind A^T · grad) skip the zero rows
      * without another pass over the result. */
     uint8_t *c_row_nonzero;
+    /* Non-zero: store log_softmax over each row of (A·B + bias) instead of the row itself — the
+     * `F.log_softmax(x, dim=1)` that ends the reference model (pygcn/models.py:52 upstream).
+     * The row must live in one wavefront's store: F <= 64 elements, or F a multiple of the 16-byte
+     * lane width v (4 fp32 / 8 bf16) with F/v <= 64 and 16-byte aligned operands; not combinable
+     * with relu / dropout.  Backward: gcn_log_softmax_backward_colsum. */
+    int32_t log_softmax;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */
@@ -188,6 +194,17 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
  * gcn_epilogue.
  */
 size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F, int dtype);
+/*
+ * Backward of the fused log_softmax epilogue with the same by-products: out = log_softmax(z) row
+ * by row, grad_pre = grad_out - exp(out) * rowsum(grad_out), colsum[f] = sum_rows grad_pre[row, f],
+ * and the row bitmap / count of grad_pre.  Rows of grad_out that are entirely zero (every vertex
+ * outside idx_train) give zero rows without `out` being read.  Same shape rules and scratch as
+ * gcn_relu_dropout_backward_colsum, with F/v <= 64 required (a row inside one wavefront).
+ */
+int gcn_log_softmax_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
+                                    float *colsum, int64_t n_rows, int64_t F, uint32_t *row_bits,
+                                    int32_t *nnz_rows, void *workspace, size_t workspace_bytes,
+                                    void *stream);
 int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
                                      uint32_t *row_bits, int32_t *nnz_rows, void *workspace,

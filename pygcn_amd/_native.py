@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 7
+GCN_ABI_VERSION = 8
 GCN_DEFAULT_ITEM_COST = 64
 GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
@@ -40,7 +40,7 @@ class GcnEpilogue(ctypes.Structure):
                 ("dropout_p", ctypes.c_float), ("seed", ctypes.c_uint64),
                 ("b_row_nonzero", ctypes.c_void_p), ("b_nnz_rows", ctypes.c_void_p),
                 ("b2", ctypes.c_void_p), ("ldb2", ctypes.c_int64), ("b_split", ctypes.c_int64),
-                ("c_row_nonzero", ctypes.c_void_p)]
+                ("c_row_nonzero", ctypes.c_void_p), ("log_softmax", ctypes.c_int32)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
@@ -49,7 +49,8 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_relu_dropout_backward", "gcn_csr_transpose_host",
            "gcn_csr_transpose_workspace_bytes", "gcn_csr_transpose_device",
            "gcn_row_normalize_device", "gcn_gemm_xw256_workspace_bytes", "gcn_gemm_xw256_f32",
-           "gcn_bwd_colsum_workspace_bytes", "gcn_relu_dropout_backward_colsum")
+           "gcn_bwd_colsum_workspace_bytes", "gcn_relu_dropout_backward_colsum",
+           "gcn_log_softmax_backward_colsum")
 
 _lib = None
 
@@ -120,6 +121,11 @@ def lib():
                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                    ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_log_softmax_backward_colsum.restype = ctypes.c_int
+    L.gcn_log_softmax_backward_colsum.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_workspace_bytes.argtypes = []
     L.gcn_gemm_xw256_f32.restype = ctypes.c_int

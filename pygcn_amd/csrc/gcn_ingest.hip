@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const IdxT *__restri
 size_t sort_temp_bytes(int64_t nnz, int bits)
 {
     size_t temp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int32_t *)nullptr, (int32_t *)nullptr,
-                                       (const uint64_t *)nullptr, (uint64_t *)nullptr, nnz, 0, bits,
-                                       (hipStream_t)0);
+    // size query only (d_temp_storage == nullptr): nothing is launched
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const int32_t *)nullptr,
+                                             (int32_t *)nullptr, (const uint64_t *)nullptr,
+                                             (uint64_t *)nullptr, nnz, 0, bits, (hipStream_t)0);
     return temp;
 }
 

@@ -86,6 +86,7 @@ struct KParams {
     const int32_t *bnnz;     // optional device scalar: number of non-zero rows of B
     int32_t n_cols;
     uint8_t *cflag;          // optional output [n_rows], pre-zeroed: 1 = stored row has a non-zero
+    int32_t log_softmax;     // store log_softmax of the row (whole row inside one store_out call)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -218,7 +219,8 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
 }
 
 // bias add + ReLU + dropout + conversion + store of one output row segment (VEC floats per lane)
-template <typename T, int VEC>
+// (a row is held by LPR consecutive lanes, VEC elements each, starting at a multiple of LPR)
+template <typename T, int VEC, int LPR>
 __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
                                           const float (&acc)[VEC], const float (&bias)[VEC])
 {
@@ -229,6 +231,22 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         if (p.relu) o[i] = fmaxf(o[i], 0.f);
     }
     if (p.drop_thresh != 0u) apply_dropout<VEC>(p, row, f, o);   // wave-uniform branch
+    if (p.log_softmax) {   // wave-uniform; the host guarantees the whole row sits in these LPR lanes
+        const bool valid = f < p.F;
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) m = valid ? fmaxf(m, o[i]) : m;
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        float se = 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) se += valid ? expf(o[i] - m) : 0.f;
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) se += __shfl_xor(se, off, kWave);
+        const float lse = m + logf(se);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o[i] -= lse;
+    }
     if (act) {
         T *dst = (T *)p.C + row * p.ldc + f;
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
@@ -283,7 +301,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
             while (e >= rend) {   // row finished (loop: rows without stored entries follow)
-                store_out<T, VEC>(p, row0 + r, f, act, acc, bias);
+                store_out<T, VEC, kWave>(p, row0 + r, f, act, acc, bias);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
                 ++r;
@@ -344,7 +362,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
     if (ROWS) {
         while (r < nr) {   // last row of the item and any trailing empty rows
-            store_out<T, VEC>(p, row0 + r, f, act, acc, bias);
+            store_out<T, VEC, kWave>(p, row0 + r, f, act, acc, bias);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             ++r;
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
-            store_out<T, VEC>(p, (int64_t)r, f, act && g == 0, acc, bias);
+            store_out<T, VEC, LPR>(p, (int64_t)r, f, act && g == 0, acc, bias);
             e0 = e1;
         }
         return;
@@ -649,7 +667,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int ru = 0; ru < RU; ++ru) {
             if (row[ru] >= 0)
-                store_out<T, VEC>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
+                store_out<T, VEC, LPR>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
         }
     }
 
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc, flags);
-        store_out<T, VEC>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
+        store_out<T, VEC, LPR>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
     }
 }
 
@@ -676,12 +694,52 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
     if (j >= p.n_long) return;
     const int64_t row = p.long_row[j];
     const int c0 = p.long_chunk0[j], c1 = p.long_chunk0[j + 1];
+    if (p.log_softmax) {
+        // F <= 512 (host check): thread t owns columns t and t + 256; block-wide max and sum
+        __shared__ float red[2][4];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        float z[2], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int f = threadIdx.x + 256 * k;
+            z[k] = -INFINITY;
+            if (f < p.F) {
+                float s = 0.f;
+                for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
+                z[k] = s + (p.bias ? p.bias[f] : 0.f);
+            }
+            m = fmaxf(m, z[k]);
+        }
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        if (lane == 0) red[0][w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) se += (threadIdx.x + 256 * k < p.F) ? expf(z[k] - m) : 0.f;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) se += __shfl_xor(se, off, kWave);
+        if (lane == 0) red[1][w] = se;
+        __syncthreads();
+        const float lse = m + logf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int f = threadIdx.x + 256 * k;
+            if (f < p.F) {
+                const float o[1] = {z[k] - lse};
+                ((T *)p.C)[row * p.ldc + f] = Elem<T, 1>::pack(o);
+                if (p.cflag != nullptr && o[0] != 0.f) p.cflag[row] = 1;
+            }
+        }
+        return;
+    }
     for (int f = threadIdx.x; f < p.F; f += blockDim.x) {
         float s = 0.f;
         for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
-        store_out<T, 1>(p, row, f, true, a, b);
+        store_out<T, 1, 1>(p, row, f, true, a, b);
     }
 }
 
@@ -714,9 +772,12 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T *__restri
 // block owns a contiguous slab of rows; thread t owns the 4 columns 4*(t % CG) (CG = F/4 column
 // groups) of every (256/CG)-th row, keeps 4 running sums, and the block writes one partial row
 // [F]; a second tiny kernel adds the partial rows in block order (deterministic, no atomics).
-// MASK = false gives a plain column sum (layer without a fused ReLU).
+// MODE 0 gives a plain column sum (layer without a fused ReLU), MODE 1 the ReLU / dropout mask,
+// MODE 2 the backward of a fused log_softmax: grad_pre = g - exp(out) * rowsum(g), the row sum by
+// xor-shuffles over the row's CG <= 64 lanes; rows of g that are entirely zero (every vertex
+// outside idx_train) are written as zeros without reading `out`.
 // ------------------------------------------------------------------------------------------
-template <typename T, int VEC, bool MASK>
+template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ grad_out,
                                                          const T *__restrict__ out,
                                                          T *__restrict__ grad_pre,
@@ -739,7 +800,7 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
         const int64_t off = r * F + VEC * cg;
         float g[VEC];
         Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
-        if (MASK) {
+        if (MODE == 1) {
             float o[VEC];
             Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
 #pragma unroll
@@ -747,6 +808,28 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
             const Raw packed = Elem<T, VEC>::pack(g);
             *(Raw *)(grad_pre + off) = packed;
             Elem<T, VEC>::unpack(packed, g);   // sums and flags follow the STORED (rounded) values
+        }
+        if (MODE == 2) {
+            float rs = 0.f;
+            bool gnz = false;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                rs += g[i];
+                gnz |= (g[i] != 0.f);
+            }
+            for (int o2 = 1; o2 < CG; o2 <<= 1) rs += __shfl_xor(rs, o2, 64);
+            const unsigned long long gb = __ballot(gnz);
+            const int ln = threadIdx.x & 63;
+            const unsigned long long gm = CG >= 64 ? ~0ull : (((1ull << CG) - 1) << (ln & ~(CG - 1)));
+            if (gb & gm) {   // uniform over the row's lanes
+                float o[VEC];
+                Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] -= expf(o[i]) * rs;
+            }
+            const Raw packed = Elem<T, VEC>::pack(g);
+            *(Raw *)(grad_pre + off) = packed;
+            Elem<T, VEC>::unpack(packed, g);
         }
         bool any = false;
 #pragma unroll
@@ -896,6 +979,9 @@ int spmm_typed(const gcn_csr_plan *plan, KParams &kp, hipStream_t s)
                         ((kp.ldb * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((kp.ldc * (int64_t)sizeof(T)) % 16 == 0);
     const unsigned nblk = (unsigned)((kp.n_total + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (kp.log_softmax && !(F <= kWave || (vec_ok && F / VECW <= kWave)))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: log_softmax needs the row inside one wavefront "
+                                  "(F <= 64, or 16-byte aligned operands with F/lane width <= 64)");
     if (kp.n_total > 0) {
         if (vec_ok) {
             const int lanes = F / VECW;
@@ -1112,6 +1198,9 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.bnnz = ep ? ep->b_nnz_rows : nullptr;
     if (kp.bflag == nullptr || kp.bnnz == nullptr) kp.bflag = nullptr, kp.bnnz = nullptr;
     kp.cflag = ep ? ep->c_row_nonzero : nullptr;
+    kp.log_softmax = (ep && ep->log_softmax) ? 1 : 0;
+    if (kp.log_softmax && (relu || drop_p > 0.f))
+        return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: log_softmax cannot be combined with relu / dropout");
     kp.n_cols = (int32_t)std::min<int64_t>(plan->n_cols, INT32_MAX);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == GCN_DTYPE_F32) return spmm_typed<float, 4>(plan, kp, s);
@@ -1130,6 +1219,7 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.b_row_nonzero = nullptr;
     ep.b_nnz_rows = nullptr;
     ep.c_row_nonzero = nullptr;
+    ep.log_softmax = 0;
     ep.b2 = nullptr;
     ep.ldb2 = 0;
     ep.b_split = 0;
@@ -1191,69 +1281,89 @@ size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F, int dtype)
     return (size_t)blocks * (size_t)F * sizeof(float) + (((size_t)n_rows + 15) & ~(size_t)15);
 }
 
-int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
-                                     float *colsum, int64_t n_rows, int64_t F, float scale,
-                                     uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
-                                     size_t workspace_bytes, void *stream)
+static int bwd_colsum_impl(const char *who, int mode, int dtype, const void *grad_out, const void *out,
+                           void *grad_pre, float *colsum, int64_t n_rows, int64_t F, float scale,
+                           uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
+                           size_t workspace_bytes, void *stream)
 {
-    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: unknown dtype");
+    char msg[160];
+    auto bad = [&](int code, const char *what) {
+        std::snprintf(msg, sizeof msg, "%s: %s", who, what);
+        return fail(code, msg);
+    };
+    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16) return bad(GCN_E_BADARG, "unknown dtype");
     if ((row_bits == nullptr) != (nnz_rows == nullptr))
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: row_bits and nnz_rows go together");
+        return bad(GCN_E_BADARG, "row_bits and nnz_rows go together");
     const int64_t vec = dtype == GCN_DTYPE_BF16 ? 8 : 4;
-    if (row_bits != nullptr && F / vec > 64) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
     if (n_rows < 0 || !colsum_shape_ok(F, dtype))
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: F must be a multiple of the "
-                                  "16-byte lane width with F/width dividing 256");
+        return bad(GCN_E_BADARG, "F must be a multiple of the 16-byte lane width with F/width dividing 256");
+    if (mode == 2 && F / vec > 64)
+        return bad(GCN_E_BADARG, "a row must fit one wavefront (F / lane width <= 64)");
+    if (row_bits != nullptr && F / vec > 64) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
     if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))
-        return fail(GCN_E_BADARG, "gcn_relu_dropout_backward_colsum: NULL pointer");
+        return bad(GCN_E_BADARG, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (nnz_rows != nullptr) {
         hipError_t e = hipMemsetAsync(nnz_rows, 0, sizeof(int32_t), s);
-        if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
+        if (e != hipSuccess) return fail_hip(e, who);
     }
     if (n_rows == 0) {
         hipError_t e = hipMemsetAsync(colsum, 0, (size_t)F * sizeof(float), s);
-        return e == hipSuccess ? 0 : fail_hip(e, "gcn_relu_dropout_backward_colsum memset");
+        return e == hipSuccess ? 0 : fail_hip(e, who);
     }
     const size_t need = gcn_bwd_colsum_workspace_bytes(n_rows, F, dtype);
-    if (workspace == nullptr || workspace_bytes < need)
-        return fail(GCN_E_WORKSPACE, "gcn_relu_dropout_backward_colsum: workspace too small");
+    if (workspace == nullptr || workspace_bytes < need) return bad(GCN_E_WORKSPACE, "workspace too small");
     if (((uintptr_t)grad_out | (uintptr_t)out | (uintptr_t)grad_pre | (uintptr_t)workspace) % 16 != 0)
-        return fail(GCN_E_ALIGN, "gcn_relu_dropout_backward_colsum: 16-byte alignment required");
+        return bad(GCN_E_ALIGN, "16-byte alignment required");
     const int64_t blocks = std::min<int64_t>((n_rows + 63) / 64, 2048);
     const int rows_per_block = (int)((n_rows + blocks - 1) / blocks);
     uint8_t *row_nonzero = row_bits ? (uint8_t *)workspace + (size_t)blocks * (size_t)F * sizeof(float)
                                     : nullptr;
     const dim3 grid((unsigned)blocks), block(256);
     float *part = (float *)workspace;
+#define GCN_LAUNCH_COLSUM(T, V, M)                                                                   \
+    hipLaunchKernelGGL((bwd_colsum_kernel<T, V, M>), grid, block, 0, s, (const T *)grad_out,         \
+                       (const T *)out, (T *)grad_pre, part, n_rows, (int)F, scale, rows_per_block,   \
+                       row_nonzero, nnz_rows)
     if (dtype == GCN_DTYPE_F32) {
-        if (out != nullptr)
-            hipLaunchKernelGGL((bwd_colsum_kernel<float, 4, true>), grid, block, 0, s,
-                               (const float *)grad_out, (const float *)out, (float *)grad_pre, part,
-                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
-        else
-            hipLaunchKernelGGL((bwd_colsum_kernel<float, 4, false>), grid, block, 0, s,
-                               (const float *)grad_out, (const float *)nullptr, (float *)nullptr, part,
-                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+        if (mode == 2) GCN_LAUNCH_COLSUM(float, 4, 2);
+        else if (mode == 1) GCN_LAUNCH_COLSUM(float, 4, 1);
+        else GCN_LAUNCH_COLSUM(float, 4, 0);
     } else {
-        if (out != nullptr)
-            hipLaunchKernelGGL((bwd_colsum_kernel<bf16_t, 8, true>), grid, block, 0, s,
-                               (const bf16_t *)grad_out, (const bf16_t *)out, (bf16_t *)grad_pre, part,
-                               n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
-        else
-            hipLaunchKernelGGL((bwd_colsum_kernel<bf16_t, 8, false>), grid, block, 0, s,
-                               (const bf16_t *)grad_out, (const bf16_t *)nullptr, (bf16_t *)nullptr,
-                               part, n_rows, (int)F, scale, rows_per_block, row_nonzero, nnz_rows);
+        if (mode == 2) GCN_LAUNCH_COLSUM(bf16_t, 8, 2);
+        else if (mode == 1) GCN_LAUNCH_COLSUM(bf16_t, 8, 1);
+        else GCN_LAUNCH_COLSUM(bf16_t, 8, 0);
     }
+#undef GCN_LAUNCH_COLSUM
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((F + 31) / 32)), dim3(1024), 0, s,
                        (const float *)workspace, colsum, (int)blocks, (int)F);
     if (row_bits != nullptr)
         hipLaunchKernelGGL(pack_row_flags_kernel, dim3((unsigned)((((n_rows + 31) >> 5) + 255) / 256)),
                            dim3(256), 0, s, (const uint8_t *)row_nonzero, row_bits, n_rows);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail_hip(e, "gcn_relu_dropout_backward_colsum launch");
+    if (e != hipSuccess) return fail_hip(e, who);
     return 0;
+}
+
+int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
+                                     float *colsum, int64_t n_rows, int64_t F, float scale,
+                                     uint32_t *row_bits, int32_t *nnz_rows, void *workspace,
+                                     size_t workspace_bytes, void *stream)
+{
+    return bwd_colsum_impl("gcn_relu_dropout_backward_colsum", out != nullptr ? 1 : 0, dtype, grad_out,
+                           out, grad_pre, colsum, n_rows, F, scale, row_bits, nnz_rows, workspace,
+                           workspace_bytes, stream);
+}
+
+int gcn_log_softmax_backward_colsum(int dtype, const void *grad_out, const void *out, void *grad_pre,
+                                    float *colsum, int64_t n_rows, int64_t F, uint32_t *row_bits,
+                                    int32_t *nnz_rows, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    if (out == nullptr)
+        return fail(GCN_E_BADARG, "gcn_log_softmax_backward_colsum: NULL pointer");
+    return bwd_colsum_impl("gcn_log_softmax_backward_colsum", 2, dtype, grad_out, out, grad_pre, colsum,
+                           n_rows, F, 1.f, row_bits, nnz_rows, workspace, workspace_bytes, stream);
 }
 
 int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,

@@ -47,7 +47,7 @@ class GraphConvolution(Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj, relu=False, dropout=0.0):
+    def forward(self, input, adj, relu=False, dropout=0.0, log_softmax=False):
         """support = input @ W (MFMA GEMM via torch.mm), output = adj @ support (HIP SpMM),
         + bias fused into the SpMM's store.  `adj`: CSRGraph, torch sparse COO/CSR (converted
         once and cached on the tensor), a ShardedGraph (multi-GPU row block), or a dense [N,N]
@@ -56,7 +56,22 @@ class GraphConvolution(Module):
 
         `relu=True` / `dropout=p` (extensions; the defaults are the reference's behaviour) apply
         the ReLU and the training-mode dropout that follow the layer in the model (models.py:48,50
-        upstream) inside the kernel's store; `dropout` requires `relu`."""
+        upstream) inside the kernel's store; `dropout` requires `relu`.  `log_softmax=True` returns
+        F.log_softmax(output, dim=-1) (models.py:52 upstream), computed in the same store when the
+        row fits one wavefront and by torch otherwise."""
+        if log_softmax:
+            if relu or dropout > 0.0:
+                raise RuntimeError("log_softmax cannot be combined with relu / dropout")
+            if (input.dim() == 2 and not isinstance(adj, ShardedGraph) and input.is_cuda
+                    and not (isinstance(adj, torch.Tensor) and adj.layout == torch.strided)
+                    and input.dtype in (torch.float32, torch.bfloat16)
+                    and (self.out_features <= 64
+                         or (self.out_features % (16 // input.element_size()) == 0
+                             and self.out_features // (16 // input.element_size()) <= 64))):
+                _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
+                return GraphConvFunction.apply(input, self.weight, self.bias, as_graph(adj), False,
+                                               0.0, 0, True)
+            return torch.nn.functional.log_softmax(self.forward(input, adj), dim=-1)
         if input.dim() == 3:
             out = self._forward_batched(input, adj, relu)
             return torch.nn.functional.dropout(out, dropout, True) if dropout > 0.0 else out

@@ -8,7 +8,6 @@ import os
 import sys
 
 import torch.nn as nn
-import torch.nn.functional as F
 
 if not __package__:   # flat import, the reference's convention (`from models import GCN`)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +26,9 @@ class GCN(nn.Module):
     def forward(self, x, adj):
         # F.dropout(F.relu(gc1(x, adj)), p, training) with ReLU and dropout fused into the SpMM store
         x = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
-        x = self.gc2(x, adj)
-        return F.log_softmax(x, dim=-1)   # dim=1 for the reference's [N, C]; last dim if batched
+        # F.log_softmax(gc2(x, adj), dim=1) — in the SpMM's store when a row fits one wavefront
+        # (dim=1 for the reference's [N, C]; the last dim if batched)
+        return self.gc2(x, adj, log_softmax=True)
 
 
 class GCNStack(nn.Module):

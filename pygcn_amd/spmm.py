@@ -27,7 +27,7 @@ def set_timing_records(records):
 
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
-             b_hint=None, B2=None, c_flags=None):
+             b_hint=None, B2=None, c_flags=None, log_softmax=False):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
@@ -36,7 +36,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     `B2`: optional second block of the dense operand — the operand is then [B; B2] stacked by rows
     without being materialised (the sharded path's own rows | halo rows).
     `c_flags`: optional uint8 [n_rows] tensor of ZEROS; the kernel sets c_flags[r] = 1 where the
-    stored row r has a non-zero element (gcn_epilogue.c_row_nonzero)."""
+    stored row r has a non-zero element (gcn_epilogue.c_row_nonzero).
+    `log_softmax`: store log_softmax over each row of A·B + bias (`F.log_softmax(x, dim=1)`, the
+    reference model's last line) — see can_fuse_log_softmax() for the shapes that allow it."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -86,7 +88,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  B2.data_ptr() if B2 is not None and B2.numel() else None,
                                  B2.stride(0) if B2 is not None and B2.numel() else 0,
                                  B.shape[0] if B2 is not None else 0,
-                                 c_flags.data_ptr() if c_flags is not None else None)
+                                 c_flags.data_ptr() if c_flags is not None else None,
+                                 int(bool(log_softmax)))
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -95,6 +98,16 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
             rec.append((tag, ev0, ev1, graph))
     _native.check(rc, "gcn_spmm_csr_ep")
     return out
+
+
+def can_fuse_log_softmax(B):
+    """True when the log_softmax over the rows of A·B can run inside the SpMM's store: the whole
+    row must sit in one wavefront (F <= 64, or 16-byte lanes with F / lane width <= 64)."""
+    F = B.shape[-1]
+    v = 16 // B.element_size()
+    return B.dim() == 2 and B.dtype in _DTYPES and (
+        F <= 64 or (F % v == 0 and F // v <= 64 and B.stride(1) == 1
+                    and (B.stride(0) * B.element_size()) % 16 == 0 and B.data_ptr() % 16 == 0))
 
 
 def relu_dropout_backward(grad_out, out, scale=1.0):
@@ -113,9 +126,11 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
     return res
 
 
-def backward_with_colsum(grad_out, out=None, scale=1.0):
-    """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 [N, F] tensors
-    (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.  The
+def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False):
+    """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 / bf16 [N, F]
+    tensors (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
+    `log_softmax=True`: `out` holds log-probabilities and grad_pre = grad_out - exp(out) *
+    rowsum(grad_out) (C-ABI gcn_log_softmax_backward_colsum; rows need F / lane width <= 64).  The
     hint — (row bitmap int32 [ceil(N/32)], nnz_rows int32 [1]) or None when F > 256 — can be handed to
     spmm_csr(b_hint=...) when grad_pre is the dense operand of the following product.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
@@ -127,7 +142,9 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
             or L.gcn_bwd_colsum_workspace_bytes(grad_out.shape[0], grad_out.shape[1],
                                                 _DTYPES[grad_out.dtype]) == 0
             or (out is not None and (out.dtype != grad_out.dtype or not out.is_contiguous()
-                                     or out.shape != grad_out.shape))):
+                                     or out.shape != grad_out.shape))
+            or (log_softmax and (out is None
+                                 or grad_out.shape[1] // (16 // grad_out.element_size()) > 64))):
         return None
     n, F = grad_out.shape
     grad_pre = torch.empty_like(grad_out) if out is not None else grad_out
@@ -139,12 +156,19 @@ def backward_with_colsum(grad_out, out=None, scale=1.0):
     ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F, _DTYPES[grad_out.dtype])
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
-        rc = L.gcn_relu_dropout_backward_colsum(
-            _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr() if out is not None else None,
-            grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
-            hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None,
-            ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
-    _native.check(rc, "gcn_relu_dropout_backward_colsum")
+        if log_softmax:
+            rc = L.gcn_log_softmax_backward_colsum(
+                _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr(), grad_pre.data_ptr(),
+                colsum.data_ptr(), n, F, hint[0].data_ptr(), hint[1].data_ptr(),
+                ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = L.gcn_relu_dropout_backward_colsum(
+                _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr() if out is not None else None,
+                grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
+                hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None,
+                ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_log_softmax_backward_colsum" if log_softmax
+                  else "gcn_relu_dropout_backward_colsum")
     return grad_pre, colsum.to(grad_out.dtype), hint
 
 
@@ -161,15 +185,19 @@ def row_bitmap(B):
     return w, nz.sum().to(torch.int32).reshape(1)
 
 
-def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias):
-    """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask and
-    (optionally) produce the bias gradient, in one HIP pass when the shape allows.  Returns
-    (grad_pre, grad_bias, row-sparsity hint or None)."""
+def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False):
+    """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask (or
+    the log_softmax backward) and (optionally) produce the bias gradient, in one HIP pass when the
+    shape allows.  Returns (grad_pre, grad_bias, row-sparsity hint or None)."""
     grad_bias = None
-    if want_bias:
-        fused = backward_with_colsum(grad_out.contiguous(), out if relu else None, scale)
+    if want_bias or log_softmax:
+        fused = backward_with_colsum(grad_out.contiguous(), out if (relu or log_softmax) else None,
+                                     scale, log_softmax)
         if fused is not None:
-            return fused
+            return fused if want_bias else (fused[0], None, fused[2])
+    if log_softmax:   # shapes outside the kernel's envelope (e.g. 7 classes): torch ops
+        g32, o32 = grad_out.float(), out.float()
+        grad_out = (g32 - o32.exp() * g32.sum(1, keepdim=True)).to(grad_out.dtype)
     if relu:
         grad_out = relu_dropout_backward(grad_out, out, scale)
     if want_bias:
@@ -338,15 +366,20 @@ class GraphConvFunction(torch.autograd.Function):
     5 % and 16 % of the rows at bench config C4."""
 
     @staticmethod
-    def forward(ctx, input, weight, bias, graph, relu=False, dropout_p=0.0, seed=0):
+    def forward(ctx, input, weight, bias, graph, relu=False, dropout_p=0.0, seed=0,
+                log_softmax=False):
         if dropout_p > 0.0 and not relu:
             raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
+        if log_softmax and relu:
+            raise RuntimeError("log_softmax cannot be combined with the fused ReLU / dropout")
         ctx.graph = graph
         ctx.relu = bool(relu)
+        ctx.log_softmax = bool(log_softmax)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         support = _dense_forward(input, weight)
-        out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
-        if relu:
+        out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
+                       log_softmax=log_softmax)
+        if relu or log_softmax:
             ctx.save_for_backward(input, weight, out)
         else:
             ctx.save_for_backward(input, weight)
@@ -355,11 +388,12 @@ class GraphConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         input, weight = ctx.saved_tensors[:2]
-        out = ctx.saved_tensors[2] if ctx.relu else None
+        out = ctx.saved_tensors[2] if (ctx.relu or ctx.log_softmax) else None
         need_in, need_w, need_b = ctx.needs_input_grad[:3]
-        grad_pre, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale, need_b)
+        grad_pre, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale, need_b,
+                                                       ctx.log_softmax)
         if not (need_in or need_w):
-            return None, None, grad_bias, None, None, None, None
+            return None, None, grad_bias, None, None, None, None, None
         graph_t = ctx.graph.t()
         n = graph_t.shape[0]
         c_flags = rows = None
@@ -373,7 +407,7 @@ class GraphConvFunction(torch.autograd.Function):
             if rows.numel() * 3 >= n:
                 rows = None
         grad_in, grad_w = _dense_grads(input, weight, grad_sup, need_in, need_w, rows)
-        return grad_in, grad_w, grad_bias, None, None, None, None
+        return grad_in, grad_w, grad_bias, None, None, None, None, None
 
 
 def spmm(adj, dense, bias=None):

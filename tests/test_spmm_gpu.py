@@ -748,3 +748,94 @@ def test_layer_backward_row_compaction(oracle, dev):
     for c, d, t in zip(compact, dense, two_node):
         assert torch.equal(d, t)
         assert_normwise(c.cpu(), d.cpu().numpy(), TOL, "compacted vs dense backward")
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (200, torch.float32), (64, torch.float32),
+                                     (16, torch.float32), (7, torch.float32), (33, torch.float32),
+                                     (128, torch.bfloat16), (512, torch.bfloat16)])
+def test_fused_log_softmax_epilogue(oracle, dev, F, dtype):
+    """gcn_epilogue.log_softmax: the stored rows are log_softmax(A·B + bias) — wide, narrow
+    (row-per-lane-group, medium rows, VEC = 1 fallback) and long-row reduce paths; empty rows
+    give log_softmax(bias)."""
+    from pygcn_amd import spmm_csr
+    a = _skewed_csr(oracle, 2500, 2200, 6, seed=F + 21, empties=100,
+                    hubs=((3, 1200), (900, 300), (901, 40)))
+    g = _graph(a, dev)
+    gen = torch.Generator(device=dev).manual_seed(F)
+    B = (3.0 * torch.randn(2200, F, generator=gen, device=dev)).to(dtype)
+    bias = torch.randn(F, generator=gen, device=dev)
+    got = spmm_csr(g, B, bias=bias, log_softmax=True)
+    z = a.matmul(B.float().cpu().numpy()).astype(np.float64) + bias.cpu().numpy().astype(np.float64)
+    ref = z - z.max(1, keepdims=True)
+    ref = ref - np.log(np.exp(ref).sum(1, keepdims=True))
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else TOL
+    assert_normwise(got.float().cpu(), ref.astype(np.float32), tol, "fused log_softmax")
+    if dtype == torch.float32:   # rows are normalised: logsumexp(row) = 0
+        assert float(torch.logsumexp(got.double(), 1).abs().max()) < 1e-5
+    with pytest.raises(RuntimeError, match="log_softmax"):
+        spmm_csr(g, B, bias=bias, relu=True, log_softmax=True)
+    if dtype == torch.float32:
+        wide = torch.randn(2200, 300, device=dev)
+        with pytest.raises(RuntimeError, match="one wavefront"):
+            spmm_csr(g, wide, log_softmax=True)
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (16, torch.float32),
+                                     (128, torch.bfloat16)])
+def test_log_softmax_backward_with_colsum(dev, F, dtype):
+    """gcn_log_softmax_backward_colsum against torch's log_softmax autograd, with mostly-zero
+    gradient rows (the idx_train pattern) and the by-products (column sums, row bitmap, count)."""
+    from pygcn_amd.spmm import backward_with_colsum, row_bitmap
+    n = 5000
+    gen = torch.Generator(device=dev).manual_seed(F)
+    z = (2.0 * torch.randn(n, F, generator=gen, device=dev)).requires_grad_(True)
+    logp = torch.log_softmax(z, 1)
+    g = torch.randn(n, F, generator=gen, device=dev)
+    g = g * (torch.rand(n, 1, generator=gen, device=dev) < 0.05)
+    logp.backward(g)
+    ref = z.grad
+    gp, cs, hint = backward_with_colsum(g.to(dtype).contiguous(), logp.detach().to(dtype).contiguous(),
+                                        log_softmax=True)
+    if dtype == torch.float32:
+        assert_normwise(gp.cpu(), ref.cpu().numpy(), TOL, "log_softmax backward")
+        assert_normwise(cs.cpu(), ref.sum(0).cpu().numpy(), 1e-4, "bias gradient")
+    else:
+        assert_normwise(gp.float().cpu(), ref.cpu().numpy(), 2.0 ** -6, "log_softmax backward bf16")
+    bits, cnt = hint
+    rb, rc = row_bitmap(gp)
+    assert torch.equal(bits, rb) and int(cnt) == int(rc)
+    assert int(cnt) == int((g != 0).any(1).sum())       # zero gradient rows stay exactly zero
+
+
+def test_model_uses_fused_log_softmax_and_matches_torch(oracle, dev):
+    """GCN.forward ends in the fused epilogue; output and every parameter gradient equal the
+    unfused composition F.log_softmax(gc2(...)) (7 classes: torch backward fallback; 64 classes:
+    HIP backward)."""
+    import importlib
+    from pygcn_amd import GCN
+    S = importlib.import_module("pygcn_amd.spmm")
+    a = _skewed_csr(oracle, 3000, 3000, 5, seed=77, empties=20, hubs=((9, 700),))
+    g = _graph(a, dev)
+    for nclass in (7, 64):
+        torch.manual_seed(3)
+        model = GCN(40, 32, nclass, 0.0).to(dev)
+        x = torch.randn(3000, 40, device=dev)
+        idx = torch.arange(0, 3000, 20, device=dev)
+        lab = torch.randint(0, nclass, (idx.numel(),), device=dev)
+        seen = []
+        orig = S.spmm_csr
+        S.spmm_csr = lambda *a_, **k: (seen.append(k.get("log_softmax", False)), orig(*a_, **k))[1]
+        try:
+            out = model(x, g)
+        finally:
+            S.spmm_csr = orig
+        assert any(seen), "the fused log_softmax epilogue was not used"
+        torch.nn.functional.nll_loss(out[idx], lab).backward()
+        got = [p.grad.clone() for p in model.parameters()]
+        model.zero_grad()
+        h = model.gc1(x, g, relu=True)
+        ref_out = torch.log_softmax(model.gc2(h, g), 1)
+        torch.nn.functional.nll_loss(ref_out[idx], lab).backward()
+        assert_normwise(out.detach().cpu(), ref_out.detach().cpu().numpy(), TOL, "fused output")
+        for a_, p in zip(got, model.parameters()):
+            assert_normwise(a_.cpu(), p.grad.cpu().numpy(), 2e-5, "fused gradients")
