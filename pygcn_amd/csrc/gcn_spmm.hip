@@ -220,7 +220,9 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
 
 // bias add + ReLU + dropout + conversion + store of one output row segment (VEC floats per lane)
 // (a row is held by LPR consecutive lanes, VEC elements each, starting at a multiple of LPR)
-template <typename T, int VEC, int LPR>
+// XEPI = false compiles the log_softmax / output-row-flag code out: the plain instantiations keep
+// the register budget they were tuned with (wide fp32: 62 VGPRs; the extras cost 8-15 more)
+template <typename T, int VEC, int LPR, bool XEPI>
 __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
                                           const float (&acc)[VEC], const float (&bias)[VEC])
 {
@@ -231,7 +233,7 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         if (p.relu) o[i] = fmaxf(o[i], 0.f);
     }
     if (p.drop_thresh != 0u) apply_dropout<VEC>(p, row, f, o);   // wave-uniform branch
-    if (p.log_softmax) {   // wave-uniform; the host guarantees the whole row sits in these LPR lanes
+    if (XEPI && p.log_softmax) {   // wave-uniform; the host guarantees the whole row sits in these LPR lanes
         const bool valid = f < p.F;
         float m = -INFINITY;
 #pragma unroll
@@ -240,10 +242,10 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         for (int off = 1; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
         float se = 0.f;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) se += valid ? expf(o[i] - m) : 0.f;
+        for (int i = 0; i < VEC; ++i) se += valid ? __expf(o[i] - m) : 0.f;   // arguments <= 0
 #pragma unroll
         for (int off = 1; off < LPR; off <<= 1) se += __shfl_xor(se, off, kWave);
-        const float lse = m + logf(se);
+        const float lse = m + __logf(se);   // se in [1, F]: hardware exp2 / log2, ~1e-7 absolute
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o[i] -= lse;
     }
@@ -251,7 +253,7 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         T *dst = (T *)p.C + row * p.ldc + f;
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
     }
-    if (p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
+    if (XEPI && p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) nz |= (o[i] != 0.f);
@@ -276,7 +278,7 @@ __device__ __forceinline__ u32x4 row_load16(uint64_t base, uint32_t nbytes, uint
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
 }
 
-template <typename T, int VEC, int D, bool ROWS, bool FLAGS>
+template <typename T, int VEC, int D, bool ROWS, bool FLAGS, bool XEPI>
 __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__restrict__ colp,
                                             const float *__restrict__ valp, int ne, int lane,
                                             unsigned ld_off_bytes, float (&acc)[VEC],
@@ -301,7 +303,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
             while (e >= rend) {   // row finished (loop: rows without stored entries follow)
-                store_out<T, VEC, kWave>(p, row0 + r, f, act, acc, bias);
+                store_out<T, VEC, kWave, XEPI>(p, row0 + r, f, act, acc, bias);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
                 ++r;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
     if (ROWS) {
         while (r < nr) {   // last row of the item and any trailing empty rows
-            store_out<T, VEC, kWave>(p, row0 + r, f, act, acc, bias);
+            store_out<T, VEC, kWave, XEPI>(p, row0 + r, f, act, acc, bias);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             ++r;
@@ -370,7 +372,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
 }
 
-template <typename T, int VEC, typename IdxT, int D, bool FLAGS>
+template <typename T, int VEC, typename IdxT, int D, bool FLAGS, bool XEPI>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParams p)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
         const int row = p.chunk_row[item];
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
-        wide_stream<T, VEC, D, false, FLAGS>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
+        wide_stream<T, VEC, D, false, FLAGS, XEPI>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
                                       ld_off_bytes, acc, 0, 0, 0, f, act, bias);
         if (act) {
             float *dst = p.partial + (int64_t)item * p.F + f;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
 #pragma unroll
         for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
     }
-    wide_stream<T, VEC, D, true, FLAGS>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
+    wide_stream<T, VEC, D, true, FLAGS, XEPI>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
                                  nr, (int64_t)ra, f, act, bias);
 }
 
@@ -525,7 +527,7 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
     }
 }
 
-template <typename T, int VEC, int LPR, typename IdxT>
+template <typename T, int VEC, int LPR, typename IdxT, bool XEPI>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KParams p)
 {
     constexpr int U = 4;
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
-            store_out<T, VEC, LPR>(p, (int64_t)r, f, act && g == 0, acc, bias);
+            store_out<T, VEC, LPR, XEPI>(p, (int64_t)r, f, act && g == 0, acc, bias);
             e0 = e1;
         }
         return;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int ru = 0; ru < RU; ++ru) {
             if (row[ru] >= 0)
-                store_out<T, VEC, LPR>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
+                store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
         }
     }
 
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc, flags);
-        store_out<T, VEC, LPR>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
+        store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
     }
 }
 
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
         for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
-        store_out<T, 1, 1>(p, row, f, true, a, b);
+        store_out<T, 1, 1, true>(p, row, f, true, a, b);
     }
 }
 
@@ -920,12 +922,18 @@ __global__ __launch_bounds__(1024) void colsum_finish_kernel(const float *__rest
 template <typename T, int VEC, int LPR>
 void launch_narrow(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
-    if (is64)
-        hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, int64_t>), grid,
-                           dim3(kWave * kWavesPerBlock), 0, s, kp);
-    else
-        hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, int32_t>), grid,
-                           dim3(kWave * kWavesPerBlock), 0, s, kp);
+    const dim3 block(kWave * kWavesPerBlock);
+    const bool xepi = kp.log_softmax || kp.cflag != nullptr;   // the instantiation with the extras
+#define GCN_LAUNCH_NARROW(I, X) \
+    hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, I, X>), grid, block, 0, s, kp)
+    if (xepi) {
+        if (is64) GCN_LAUNCH_NARROW(int64_t, true);
+        else GCN_LAUNCH_NARROW(int32_t, true);
+    } else {
+        if (is64) GCN_LAUNCH_NARROW(int64_t, false);
+        else GCN_LAUNCH_NARROW(int32_t, false);
+    }
+#undef GCN_LAUNCH_NARROW
 }
 
 template <typename T, int VEC>
@@ -947,17 +955,27 @@ void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
     constexpr int D = 8;
     const dim3 block(kWave * kWavesPerBlock);
+    const bool xepi = kp.log_softmax || kp.cflag != nullptr;
+#define GCN_LAUNCH_WIDE(I, FL, X) \
+    hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, I, D, FL, X>), grid, block, 0, s, kp)
     if (kp.bflag != nullptr) {   // row-sparse operand hint: the variant that reads the row flags
-        if (is64)
-            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D, true>), grid, block, 0, s, kp);
-        else
-            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D, true>), grid, block, 0, s, kp);
+        if (xepi) {
+            if (is64) GCN_LAUNCH_WIDE(int64_t, true, true);
+            else GCN_LAUNCH_WIDE(int32_t, true, true);
+        } else {
+            if (is64) GCN_LAUNCH_WIDE(int64_t, true, false);
+            else GCN_LAUNCH_WIDE(int32_t, true, false);
+        }
     } else {
-        if (is64)
-            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int64_t, D, false>), grid, block, 0, s, kp);
-        else
-            hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, int32_t, D, false>), grid, block, 0, s, kp);
+        if (xepi) {
+            if (is64) GCN_LAUNCH_WIDE(int64_t, false, true);
+            else GCN_LAUNCH_WIDE(int32_t, false, true);
+        } else {
+            if (is64) GCN_LAUNCH_WIDE(int64_t, false, false);
+            else GCN_LAUNCH_WIDE(int32_t, false, false);
+        }
     }
+#undef GCN_LAUNCH_WIDE
 }
 
 int next_pow2(int v)
