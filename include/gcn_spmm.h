@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 8
+#define GCN_ABI_VERSION 9
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -166,6 +166,10 @@ typedef struct gcn_epilogue {
      * lane width v (4 fp32 / 8 bf16) with F/v <= 64 and 16-byte aligned operands; not combinable
      * with relu / dropout.  Backward: gcn_log_softmax_backward_colsum. */
     int32_t log_softmax;
+    /* Optional DEVICE pointer to the dropout seed (NULL: use `seed`).  The kernel reads the seed
+     * when it runs, not when it is enqueued, so a launch captured into a hipGraph draws a fresh
+     * mask on every replay if the graph also updates *seed_dev (e.g. a captured increment). */
+    const uint64_t *seed_dev;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

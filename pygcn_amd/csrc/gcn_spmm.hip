@@ -87,6 +87,7 @@ struct KParams {
     int32_t n_cols;
     uint8_t *cflag;          // optional output [n_rows], pre-zeroed: 1 = stored row has a non-zero
     int32_t log_softmax;     // store log_softmax of the row (whole row inside one store_out call)
+    const uint64_t *seed_dev;   // optional device-resident dropout seed (overrides seed_lo/hi)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -202,15 +203,20 @@ template <int VEC>
 __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int f, float (&o)[VEC])
 {
     uint32_t r[4];
+    uint32_t k0 = p.seed_lo, k1 = p.seed_hi;
+    if (p.seed_dev != nullptr) {   // wave-uniform scalar load: the seed as of execution time
+        const uint64_t sd = *p.seed_dev;
+        k0 = (uint32_t)sd;
+        k1 = (uint32_t)(sd >> 32);
+    }
     if (VEC == 1) {
-        philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(f >> 2), 0u, p.seed_lo,
-                      p.seed_hi, r);
+        philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(f >> 2), 0u, k0, k1, r);
         o[0] = (r[f & 3] >= p.drop_thresh) ? o[0] * p.drop_scale : 0.f;
     } else {
 #pragma unroll
         for (int q = 0; q < VEC / 4; ++q) {
-            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)((f >> 2) + q), 0u,
-                          p.seed_lo, p.seed_hi, r);
+            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)((f >> 2) + q), 0u, k0,
+                          k1, r);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 o[4 * q + i] = (r[i] >= p.drop_thresh) ? o[4 * q + i] * p.drop_scale : 0.f;
@@ -1207,6 +1213,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.drop_scale = 1.f / (1.f - drop_p);
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
+    kp.seed_dev = ep ? ep->seed_dev : nullptr;
     kp.B2 = ep ? ep->b2 : nullptr;
     kp.ldb2 = ep && ep->b2 ? ep->ldb2 : 0;
     kp.b_split = (ep && ep->b2) ? (int32_t)std::min<int64_t>(ep->b_split, INT32_MAX) : INT32_MAX;
@@ -1238,6 +1245,7 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.b_nnz_rows = nullptr;
     ep.c_row_nonzero = nullptr;
     ep.log_softmax = 0;
+    ep.seed_dev = nullptr;
     ep.b2 = nullptr;
     ep.ldb2 = 0;
     ep.b_split = 0;

@@ -21,7 +21,7 @@ if not __package__:   # imported flat, the reference's convention (`from layers 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
 from pygcn_amd.spmm import (DenseMMFunction, GraphConvFunction, SpMMFunction,  # noqa: E402
-                            next_dropout_seed)
+                            dropout_seed_for)
 from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
@@ -75,7 +75,7 @@ class GraphConvolution(Module):
         if input.dim() == 3:
             out = self._forward_batched(input, adj, relu)
             return torch.nn.functional.dropout(out, dropout, True) if dropout > 0.0 else out
-        seed = next_dropout_seed() if dropout > 0.0 else 0
+        seed = dropout_seed_for(input) if dropout > 0.0 else 0
         if isinstance(adj, ShardedGraph):
             # row-block shard of a multi-GPU run: exchange + local HIP SpMM (pygcn_amd/sharded.py)
             return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),

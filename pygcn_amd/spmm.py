@@ -38,7 +38,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     `c_flags`: optional uint8 [n_rows] tensor of ZEROS; the kernel sets c_flags[r] = 1 where the
     stored row r has a non-zero element (gcn_epilogue.c_row_nonzero).
     `log_softmax`: store log_softmax over each row of A·B + bias (`F.log_softmax(x, dim=1)`, the
-    reference model's last line) — see can_fuse_log_softmax() for the shapes that allow it."""
+    reference model's last line) — see can_fuse_log_softmax() for the shapes that allow it.
+    `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
+    (hipGraph replays draw a fresh mask if the graph updates the tensor, see device_dropout_seed)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -81,6 +83,11 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
         if rec is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        seed_dev = None
+        if isinstance(seed, torch.Tensor):
+            if seed.dtype != torch.int64 or seed.numel() != 1 or seed.device != B.device:
+                raise RuntimeError("spmm_csr: a tensor seed must be one int64 on the operand's device")
+            seed_dev, seed = seed.data_ptr(), 0
         ep = _native.GcnEpilogue(bias.data_ptr() if bias is not None else None, int(bool(relu)),
                                  float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                  b_hint[0].data_ptr() if b_hint is not None else None,
@@ -89,7 +96,7 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  B2.stride(0) if B2 is not None and B2.numel() else 0,
                                  B.shape[0] if B2 is not None else 0,
                                  c_flags.data_ptr() if c_flags is not None else None,
-                                 int(bool(log_softmax)))
+                                 int(bool(log_softmax)), seed_dev)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -209,6 +216,33 @@ def next_dropout_seed():
     """64-bit seed drawn from torch's default CPU generator: reproducible under
     torch.manual_seed, no device synchronisation."""
     return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+_device_seeds = {}
+
+
+def dropout_seed_for(tensor):
+    """Seed of one fused-dropout launch on `tensor`'s device.  Normally a host integer drawn from
+    torch's CPU generator (next_dropout_seed).  While the stream is being captured into a
+    hipGraph a host seed would be frozen into the captured kernel arguments — the same mask on
+    every replay — so the launch then reads a per-device int64 tensor that an op recorded in the
+    same capture advances: every replay masks differently.  The tensor is created by the first
+    eager dropout launch on the device (the warm-up steps torch requires before a capture)."""
+    if not tensor.is_cuda:
+        return next_dropout_seed()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = tensor.device.index if tensor.device.index is not None else torch.cuda.current_device()
+    t = _device_seeds.get(key)
+    if t is None:
+        if capturing:
+            raise RuntimeError("run one training step with dropout before capturing it into a "
+                               "hipGraph (the device-resident dropout seed is created on first use)")
+        t = _device_seeds[key] = torch.full((1,), next_dropout_seed(), dtype=torch.int64,
+                                            device=tensor.device)
+    if not capturing:
+        return next_dropout_seed()
+    t.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment, wraps; recorded in the capture
+    return t
 
 
 class SpMMFunction(torch.autograd.Function):

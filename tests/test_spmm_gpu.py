@@ -839,3 +839,44 @@ def test_model_uses_fused_log_softmax_and_matches_torch(oracle, dev):
         assert_normwise(out.detach().cpu(), ref_out.detach().cpu().numpy(), TOL, "fused output")
         for a_, p in zip(got, model.parameters()):
             assert_normwise(a_.cpu(), p.grad.cpu().numpy(), 2e-5, "fused gradients")
+
+
+def test_dropout_under_hipgraph_replay_draws_fresh_masks(oracle, dev):
+    """A host seed would be frozen into a captured launch; the device-resident seed
+    (gcn_epilogue.seed_dev) is advanced by an op recorded in the same capture, so each replay
+    masks differently — and a launch with a tensor seed equals the launch with that value as a
+    host seed."""
+    from pygcn_amd import GraphConvolution, spmm_csr
+    a = _skewed_csr(oracle, 1500, 1500, 6, seed=91, hubs=((4, 600),))
+    g = _graph(a, dev)
+    g.plan()
+    B = torch.randn(1500, 64, device=dev)
+    bias = torch.rand(64, device=dev)
+    seed_t = torch.tensor([123456789012345], dtype=torch.int64, device=dev)
+    assert torch.equal(spmm_csr(g, B, bias=bias, relu=True, dropout_p=0.5, seed=seed_t),
+                       spmm_csr(g, B, bias=bias, relu=True, dropout_p=0.5, seed=123456789012345))
+    with pytest.raises(RuntimeError, match="tensor seed"):
+        spmm_csr(g, B, relu=True, dropout_p=0.5, seed=seed_t.int())
+
+    torch.manual_seed(0)
+    layer = GraphConvolution(64, 64).to(dev)
+    x = torch.randn(1500, 64, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), torch.no_grad():
+        for _ in range(2):
+            layer(x, g, relu=True, dropout=0.5)      # eager warm-up creates the device seed
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph), torch.no_grad():
+        out = layer(x, g, relu=True, dropout=0.5)
+    graph.replay()
+    first = out.clone()
+    graph.replay()
+    second = out.clone()
+    dense = layer(x, g, relu=True).detach()
+    for o in (first, second):                         # each replay is a valid inverted dropout
+        kept = o != 0
+        assert torch.allclose(o[kept], 2.0 * dense[kept], rtol=1e-6, atol=0)
+        frac = float(kept.sum()) / float((dense != 0).sum())
+        assert 0.45 < frac < 0.55
+    assert not torch.equal(first != 0, second != 0), "replays reused the same dropout mask"
