@@ -340,10 +340,11 @@ def main():
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
-            "spmm_bwd_note": "the transpose products skip all-zero rows of their dense operand "
-                             "(gradients of the idx_train loss: 5 % of the rows non-zero at layer 2, "
-                             "16 % at layer 1); `value` and `roofline` are the forward product, "
-                             "whose operand is dense",
+            "spmm_bwd_note": ("the transpose products skip all-zero rows of their dense operand "
+                              "(gradients of the idx_train loss: 5 % of the rows non-zero at layer 2, "
+                              "16 % at layer 1); `value` and `roofline` are the forward product, "
+                              "whose operand is dense") if world == 1 else
+                             "exchange of the gradient rows + local transpose product (dense operand)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),
