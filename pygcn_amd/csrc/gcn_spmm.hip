@@ -809,10 +809,17 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
         float g[VEC];
         Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
         if (MODE == 1) {
-            float o[VEC];
-            Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+            // lanes whose 16 bytes of grad_out are all zero produce zeros whatever `out` holds:
+            // they skip its load (row-sparse gradients: most of the `out` traffic disappears)
+            bool gnz = false;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] * scale : 0.f;
+            for (int i = 0; i < VEC; ++i) gnz |= (g[i] != 0.f);
+            if (gnz) {
+                float o[VEC];
+                Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] = o[i] > 0.f ? g[i] * scale : 0.f;
+            }
             const Raw packed = Elem<T, VEC>::pack(g);
             *(Raw *)(grad_pre + off) = packed;
             Elem<T, VEC>::unpack(packed, g);   // sums and flags follow the STORED (rounded) values
