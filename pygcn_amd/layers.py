@@ -21,7 +21,7 @@ if not __package__:   # imported flat, the reference's convention (`from layers 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
 from pygcn_amd.spmm import (DenseMMFunction, GraphConvFunction, SpMMFunction,  # noqa: E402
-                            dropout_seed_for)
+                            dropout_seed_for, log_softmax_fusable)
 from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
 
 
@@ -64,10 +64,7 @@ class GraphConvolution(Module):
                 raise RuntimeError("log_softmax cannot be combined with relu / dropout")
             if (input.dim() == 2 and not isinstance(adj, ShardedGraph) and input.is_cuda
                     and not (isinstance(adj, torch.Tensor) and adj.layout == torch.strided)
-                    and input.dtype in (torch.float32, torch.bfloat16)
-                    and (self.out_features <= 64
-                         or (self.out_features % (16 // input.element_size()) == 0
-                             and self.out_features // (16 // input.element_size()) <= 64))):
+                    and log_softmax_fusable(self.out_features, input.dtype)):
                 _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
                 return GraphConvFunction.apply(input, self.weight, self.bias, as_graph(adj), False,
                                                0.0, 0, True)

@@ -38,9 +38,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     `c_flags`: optional uint8 [n_rows] tensor of ZEROS; the kernel sets c_flags[r] = 1 where the
     stored row r has a non-zero element (gcn_epilogue.c_row_nonzero).
     `log_softmax`: store log_softmax over each row of A·B + bias (`F.log_softmax(x, dim=1)`, the
-    reference model's last line) — see can_fuse_log_softmax() for the shapes that allow it.
+    reference model's last line) — see log_softmax_fusable() for the shapes that allow it.
     `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
-    (hipGraph replays draw a fresh mask if the graph updates the tensor, see device_dropout_seed)."""
+    (hipGraph replays draw a fresh mask if the graph updates the tensor, see dropout_seed_for)."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -107,14 +107,14 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     return out
 
 
-def can_fuse_log_softmax(B):
-    """True when the log_softmax over the rows of A·B can run inside the SpMM's store: the whole
-    row must sit in one wavefront (F <= 64, or 16-byte lanes with F / lane width <= 64)."""
-    F = B.shape[-1]
-    v = 16 // B.element_size()
-    return B.dim() == 2 and B.dtype in _DTYPES and (
-        F <= 64 or (F % v == 0 and F // v <= 64 and B.stride(1) == 1
-                    and (B.stride(0) * B.element_size()) % 16 == 0 and B.data_ptr() % 16 == 0))
+def log_softmax_fusable(F, dtype):
+    """True when log_softmax over rows of width F can run inside the SpMM's store: the whole row
+    must sit in one wavefront (F <= 64, or 16-byte lanes with F / lane width <= 64; a freshly
+    allocated support tensor satisfies the kernel's 16-byte alignment rule)."""
+    if dtype not in _DTYPES:
+        return False
+    v = 128 // torch.finfo(dtype).bits        # elements per 16-byte lane
+    return F <= 64 or (F % v == 0 and F // v <= 64)
 
 
 def relu_dropout_backward(grad_out, out, scale=1.0):
