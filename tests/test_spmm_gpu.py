@@ -880,3 +880,57 @@ def test_dropout_under_hipgraph_replay_draws_fresh_masks(oracle, dev):
         frac = float(kept.sum()) / float((dense != 0).sum())
         assert 0.45 < frac < 0.55
     assert not torch.equal(first != 0, second != 0), "replays reused the same dropout mask"
+
+
+def test_randomized_option_combinations(oracle, dev):
+    """60 seeded random problems over the OPTIONS of gcn_spmm_csr_ep — operand hint, output row
+    flags, fused log_softmax, two-block operand, bf16, int64 row pointers — crossed with random
+    shapes and schedule knobs, each checked against the oracle product in fp64."""
+    from pygcn_amd import CSRGraph, spmm_csr
+    from pygcn_amd.spmm import log_softmax_fusable, row_bitmap
+    rng = np.random.default_rng(77)
+    for case in range(60):
+        n_rows, n_cols = int(rng.integers(1, 600)), int(rng.integers(2, 600))
+        bf16 = bool(rng.integers(0, 4) == 0)
+        F = int(rng.choice([8, 16, 64, 128, 256, 512] if bf16 else [1, 4, 7, 33, 64, 100, 128, 256, 300]))
+        deg = rng.poisson(rng.choice([0.5, 3, 10]), size=n_rows)
+        for _ in range(int(rng.integers(0, 3))):
+            deg[rng.integers(0, n_rows)] = int(rng.integers(50, 1200))
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        nnz = int(rowptr[-1])
+        col = rng.integers(0, n_cols, size=nnz).astype(np.int32)
+        val = (1.0 - rng.random(nnz)).astype(np.float32)
+        a = oracle.CSR(rowptr, col, val, (n_rows, n_cols))
+        kw = dict(item_cost=int(rng.choice([0, 8, 200])), long_thresh=int(rng.choice([0, 4, 37])))
+        rp_t = torch.from_numpy(rowptr if case % 2 else rowptr.astype(np.int32))
+        g = CSRGraph(rp_t.to(dev), torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev),
+                     (n_rows, n_cols), **kw)
+        dt = torch.bfloat16 if bf16 else torch.float32
+        B = torch.from_numpy(gin.dense((n_cols, F), 9000 + case)).to(dev)
+        B = (B * (torch.rand(n_cols, 1, device=dev) < rng.choice([0.05, 0.5, 1.0]))).to(dt)
+        bias = torch.from_numpy(gin.dense((F,), 9500 + case)).to(dev) if case % 3 else None
+        use_ls = bool(rng.integers(0, 2)) and log_softmax_fusable(F, dt)
+        use_hint, use_flags, use_b2 = (bool(rng.integers(0, 2)) for _ in range(3))
+        opts = {}
+        if use_hint:
+            opts["b_hint"] = row_bitmap(B)
+        flags = torch.zeros(n_rows, dtype=torch.uint8, device=dev) if use_flags else None
+        lhs = B
+        if use_b2:
+            split = int(rng.integers(0, n_cols + 1))
+            lhs, opts["B2"] = B[:split], B[split:].clone()
+        out = spmm_csr(g, lhs, bias=bias, c_flags=flags, log_softmax=use_ls, **opts)
+        ref = a.matmul(B.float().cpu().numpy()).astype(np.float64)
+        if bias is not None:
+            ref = ref + bias.cpu().numpy().astype(np.float64)
+        scale = max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-30)
+        if use_ls:
+            ref = ref - ref.max(1, keepdims=True)
+            ref = ref - np.log(np.exp(ref).sum(1, keepdims=True))
+            scale = max(scale, float(np.abs(ref).max()))
+        what = f"case {case}: {n_rows}x{n_cols} F={F} {dt} {kw} ls={use_ls} hint={use_hint} " \
+               f"flags={use_flags} b2={use_b2}"
+        err = float(np.abs(out.float().cpu().numpy().astype(np.float64) - ref).max()) if ref.size else 0.0
+        assert err <= (2.0 ** -7 if bf16 else 1e-5) * scale, f"{what}: err {err:.3e} scale {scale:.3e}"
+        if use_flags:
+            assert torch.equal(flags.bool(), (out != 0).any(1)), what
