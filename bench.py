@@ -13,7 +13,8 @@ Printed JSON (rank 0, one line):
   value        = fwd SpMM throughput, nnz(A_hat) / mean duration of the forward `gcn_spmm_csr`
                  launches inside the timed region, in GEdge/s (all ranks' edges / slowest rank at
                  N > 1, where the window includes the exchange step — halo P2P or all-gather — the
-                 product depends on)
+                 product depends on; for layer 1 in halo mode the window is the GEMM of the held
+                 feature halo rows + the local product, see pygcn_amd/sharded.py)
   ms_per_step  = fwd+bwd ms/epoch (wall, max over ranks)
   roofline     = algorithmic bytes of one forward SpMM launch / its mean duration vs 8 TB/s HBM
   cpu_baseline = the oracle's OpenMP CSR SpMM (a CPU port of the reference's call,
@@ -334,7 +335,13 @@ def main():
                        "nodes": n_total, "nnz": nnz_total, "feat_dim": feat,
                        "parallelism": (f"row-block x{world}, {args.exchange} exchange, rank0 "
                                        f"receives {adj.exchange_rows()[0]} of "
-                                       f"{adj.exchange_rows()[1]} remote rows per product")
+                                       f"{adj.exchange_rows()[1]} remote rows per product"
+                                       + ("; the halo rows of the constant feature matrix are "
+                                          "exchanged once before the timed region and held (like "
+                                          "the adjacency block), so layer 1 recomputes their GEMM "
+                                          "locally instead of exchanging: 2 exchanges per epoch "
+                                          "(layer 2 forward / backward), not 4"
+                                          if args.exchange == "halo" else ""))
                        if world > 1 else "single GPU",
                        "mode": "spmm-only" if args.spmm_only else "train-epoch"},
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
@@ -344,7 +351,7 @@ def main():
                               "(gradients of the idx_train loss: 5 % of the rows non-zero at layer 2, "
                               "16 % at layer 1); `value` and `roofline` are the forward product, "
                               "whose operand is dense") if world == 1 else
-                             "exchange of the gradient rows + local transpose product (dense operand)",
+                             "layer 2: exchange of the gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),

@@ -22,7 +22,8 @@ if not __package__:   # imported flat, the reference's convention (`from layers 
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
 from pygcn_amd.spmm import (DenseMMFunction, GraphConvFunction, SpMMFunction,  # noqa: E402
                             dropout_seed_for, log_softmax_fusable)
-from pygcn_amd.sharded import ShardedGraph, ShardedSpMMFunction  # noqa: E402
+from pygcn_amd.sharded import (ShardedGraph, ShardedInputLayerFunction,  # noqa: E402
+                               ShardedSpMMFunction)
 
 
 class GraphConvolution(Module):
@@ -75,6 +76,9 @@ class GraphConvolution(Module):
         seed = dropout_seed_for(input) if dropout > 0.0 else 0
         if isinstance(adj, ShardedGraph):
             # row-block shard of a multi-GPU run: exchange + local HIP SpMM (pygcn_amd/sharded.py)
+            if adj.is_constant_input(input):     # feature block: halo rows held, no exchange
+                return ShardedInputLayerFunction.apply(adj, input, adj.constant_halo(input),
+                                                       self.weight, self.bias, relu, dropout, seed)
             return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
                                              self.bias, relu, dropout, seed)
         _require_cuda(input, "input")

@@ -24,16 +24,27 @@ same layer (reference pygcn/layers.py:32-38):
     no remote rank at all (self-loop-only vertices), and xGMI is point-to-point, so sending only
     what is needed, directly owner -> consumer, is the right shape for it.
 
+  * Constant input (the feature matrix X of the first layer, `ShardedGraph.register_constant_input`):
+    its halo rows are exchanged ONCE and kept — each rank then holds the feature rows its block
+    references, like it holds its block of Â — and the first layer needs no exchange at all:
+        forward   out_r = Â_r · ([X_r ; X_halo] · W)      (the halo rows' GEMM is recomputed locally
+                                                           every step instead of being received)
+        backward  grad_W partial = (Â_r · [X_r ; X_halo])ᵀ · grad_pre_r      (summed by the gradient
+                                                           all-reduce; X needs no gradient)
+    so a 2-layer GCN epoch has 2 exchanges (layer 2 forward / backward) instead of 4.
+
 The local product is `pygcn_amd.spmm.spmm_csr` (HIP) and the local backward pass
 `pygcn_amd.spmm._grad_pre_and_bias` (HIP).  `graph_factory` / `spmm_fn` / `bwd_fn` exist so the
 partition / exchange logic can be exercised on CPU with gloo in tests/, where tests/ (never this
 package) supplies CPU stand-ins (the oracle) for them.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
 from .graph import CSRGraph
-from .spmm import _grad_pre_and_bias, spmm_csr
+from .spmm import _dense_forward, _grad_pre_and_bias, _weight_grad, spmm_csr
 
 
 def partition_rows(rowptr, world):
@@ -189,6 +200,9 @@ class ShardedGraph:
                                              (self.n_local, n_pad), **plan_kw), None))
         (self.A, self.halo), (self.At, self.halo_t) = blocks
         self.timing = None    # optional list: (tag, start_event, end_event) per exchange+product
+        self._const_ref = None      # weakref to the registered constant input (feature matrix)
+        self._const_halo = None     # (version, halo rows) of that tensor
+        self.n_const_exchanges = 0
 
     @classmethod
     def from_global_csr(cls, rowptr, col, val, n, rank, world, device=None, group=None, **kw):
@@ -215,11 +229,38 @@ class ShardedGraph:
         dist.all_gather_into_tensor(out, slot, group=self.group)   # in-place form
         return out
 
+    # ---------------------------------------------------------------- constant input
+    def register_constant_input(self, t):
+        """Declare `t` [n_local, F] (this rank's rows of the input feature matrix) constant across
+        steps: its halo rows are exchanged once (and again only if `t` is modified in place)."""
+        if self._const_ref is None or self._const_ref() is not t:
+            self._const_ref, self._const_halo = weakref.ref(t), None
+
+    def is_constant_input(self, t):
+        return (self.exchange_mode == "halo" and self._const_ref is not None
+                and self._const_ref() is t and not t.requires_grad)
+
+    def constant_halo(self, t):
+        """Halo rows of the registered constant input; collective on first use per version."""
+        if self._const_halo is None or self._const_halo[0] != t._version:
+            self._const_halo = (t._version, self.halo.exchange(t.detach()))
+            self.n_const_exchanges += 1
+        return self._const_halo[1]
+
+    def _tic(self, like):
+        if self.timing is None or not like.is_cuda:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def _toc(self, ev, tag):
+        if ev is not None:
+            ev[1].record()
+            self.timing.append((tag, ev[0], ev[1]))
+
     def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0):
-        ev = None
-        if self.timing is not None and local.is_cuda:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        ev = self._tic(local)
         kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
         if self.exchange_mode == "halo":
             halo = (self.halo_t if transpose else self.halo).exchange(local)
@@ -230,9 +271,7 @@ class ShardedGraph:
             gathered = self.all_gather_rows(local)
             out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
                              tag="bwd_local" if transpose else "fwd_local", **kw)
-        if ev is not None:
-            ev[1].record()
-            self.timing.append(("bwd" if transpose else "fwd", ev[0], ev[1]))
+        self._toc(ev, "bwd" if transpose else "fwd")
         return out
 
     def exchange_rows(self):
@@ -276,6 +315,51 @@ class ShardedSpMMFunction(torch.autograd.Function):
         return None, grad_support, grad_bias, None, None, None
 
 
+class ShardedInputLayerFunction(torch.autograd.Function):
+    """The layer on a sharded graph when its input is the registered constant feature block (no
+    gradient flows to it): no exchange in forward or backward — see the module docstring.
+
+        out_r         = Â_r · ([X_r ; X_halo] · W) + b      (+ fused ReLU / dropout)
+        grad_W (part) = (Â_r · [X_r ; X_halo])ᵀ · grad_pre_r
+
+    Both products use this rank's forward block Â_r with the two-block dense operand; the partial
+    grad_W / grad_b are summed over ranks by ShardedGCN.allreduce_grads like every other
+    parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, sg, x_local, x_halo, weight, bias, relu=False, dropout_p=0.0, seed=0):
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        ctx.relu = bool(relu)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ev = sg._tic(x_local)
+        sup_own = _dense_forward(x_local, weight)
+        sup_halo = _dense_forward(x_halo, weight) if x_halo.shape[0] else \
+            x_halo.new_empty((0, weight.shape[1]))
+        kw = {"dropout_p": dropout_p, "seed": seed + sg.rank} if dropout_p > 0.0 else {}
+        out = sg._spmm(sg.A, sup_own, bias=bias, relu=relu, tag="fwd_local", B2=sup_halo, **kw)
+        sg._toc(ev, "fwd")
+        ctx.save_for_backward(x_local, x_halo, weight, *([out] if relu else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        sg = ctx.sg
+        x_local, x_halo = ctx.saved_tensors[:2]
+        out = ctx.saved_tensors[3] if ctx.relu else None
+        grad_pre, grad_bias, _ = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
+                                         ctx.has_bias and ctx.needs_input_grad[4])
+        grad_w = None
+        if ctx.needs_input_grad[3]:
+            ev = sg._tic(grad_pre)
+            z = sg._spmm(sg.A, x_local, tag="bwd_local", B2=x_halo)   # this rank's rows of Â · X
+            sg._toc(ev, "bwd")
+            grad_w = _weight_grad(z, grad_pre.contiguous())
+        return None, None, None, grad_w, grad_bias, None, None, None
+
+
 class ShardedGCN(torch.nn.Module):
     """A replicated GCN driven on row-block shards: forward(x_local, sharded_adj)."""
 
@@ -285,7 +369,10 @@ class ShardedGCN(torch.nn.Module):
         self._flat = None
 
     def forward(self, x_local, sg=None):
-        return self.model(x_local, sg if sg is not None else self.sg)
+        sg = sg if sg is not None else self.sg
+        if sg.exchange_mode == "halo" and not x_local.requires_grad:
+            sg.register_constant_input(x_local)    # the feature rows: exchanged once, then kept
+        return self.model(x_local, sg)
 
     def nll_loss(self, logp_local, labels_local, idx_local=None):
         """This rank's share of the global-mean NLL over the (optionally index-selected) nodes of

@@ -102,6 +102,31 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         for k, v in grads.items():
             mod, name = k.split(".")
             close(getattr(getattr(model, mod), name).grad.numpy(), v, k + ".grad", rel=2e-5)
+        # the feature block is a registered constant input in halo mode: its halo rows were
+        # exchanged once; a second step exchanges nothing for layer 1; an in-place edit of the
+        # features is noticed; an input that requires grad takes the general (exchanging) path and
+        # gives the same parameter gradients
+        if exchange == "halo":
+            assert sg.n_const_exchanges == 1 and sg.is_constant_input(x_loc)
+            first = {k: v.grad.clone() for k, v in model.named_parameters()}
+            model.zero_grad()
+            smodel.nll_loss(smodel(x_loc, sg), y_loc, idx_loc).backward()
+            smodel.allreduce_grads()
+            assert sg.n_const_exchanges == 1
+            for k, v in model.named_parameters():
+                assert torch.equal(v.grad, first[k]), k
+            x_loc.mul_(1.0)
+            smodel(x_loc, sg)
+            assert sg.n_const_exchanges == 2
+            model.zero_grad()
+            xg = x_loc.clone().requires_grad_(True)
+            smodel.nll_loss(smodel(xg, sg), y_loc, idx_loc).backward()
+            smodel.allreduce_grads()
+            assert sg.n_const_exchanges == 2 and xg.grad is not None
+            for k, v in model.named_parameters():
+                close(v.grad.numpy(), first[k].numpy().astype(np.float64), k + " (general path)", rel=2e-5)
+        else:
+            assert sg.n_const_exchanges == 0 and not sg.is_constant_input(x_loc)
         # blocks are nnz-balanced and cover every stored entry exactly once
         tot = torch.tensor([float(sg.nnz_local), float(sg.At.nnz)])
         dist.all_reduce(tot)
