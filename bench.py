@@ -340,7 +340,7 @@ def main():
                                           "exchanged once before the timed region and held (like "
                                           "the adjacency block), so layer 1 recomputes their GEMM "
                                           "locally instead of exchanging: 2 exchanges per epoch "
-                                          "(layer 2 forward / backward), not 4"
+                                          "(layer 2 forward dense, layer 2 backward non-zero rows only), not 4"
                                           if args.exchange == "halo" else ""))
                        if world > 1 else "single GPU",
                        "mode": "spmm-only" if args.spmm_only else "train-epoch"},
@@ -351,7 +351,7 @@ def main():
                               "(gradients of the idx_train loss: 5 % of the rows non-zero at layer 2, "
                               "16 % at layer 1); `value` and `roofline` are the forward product, "
                               "whose operand is dense") if world == 1 else
-                             "layer 2: exchange of the gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
+                             "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),

@@ -133,6 +133,11 @@ class HaloExchange:
             assert int(self.send_idx.max()) < self.n_local and int(self.send_idx.min()) >= 0
         self.n_halo = sum(recv_counts)
         self.n_send = sum(self.send_counts)
+        # start of each peer's segment in send_idx / in the packed send buffer (peers in rank order)
+        self.send_off, acc = [], 0
+        for s in range(world):
+            self.send_off.append(acc)
+            acc += self.send_counts[s]
         # compact layout: [own rows | halo rows of rank 0 | rank 1 | ...]; remap the column ids
         halo_off, acc = [], 0
         for r in range(world):
@@ -169,15 +174,59 @@ class HaloExchange:
         _p2p_round(sends, recvs, self.group)
         return halo
 
+    def exchange_sparse(self, local, row_nonzero):
+        """The same exchange for a ROW-SPARSE operand (gradients of a loss on few labelled vertices:
+        most requested rows are entirely zero).  `row_nonzero(idx)` -> bool tensor: is row idx[i] of
+        `local` non-zero.  Only the non-zero requested rows travel, each peer's message preceded by
+        the positions of those rows in its request list; the receiver scatters them into a zeroed
+        halo buffer.  One tiny all-gather tells every rank how many rows each peer will send (the
+        only host synchronisation); every rank must call this together, like exchange()."""
+        F, dev, W = local.shape[1], local.device, self.world
+        halo = torch.zeros((self.n_halo, F), dtype=local.dtype, device=dev)
+        if W == 1:
+            return halo
+        keep = row_nonzero(self.send_idx)                                   # [n_send] bool
+        nz = torch.nonzero(keep).squeeze(1)                                 # sorted send positions
+        off = torch.tensor(self.send_off + [self.n_send], dtype=torch.int64, device=dev)
+        cut = torch.searchsorted(nz, off)                                   # split by peer
+        mine = (cut[1:] - cut[:-1]).contiguous()                            # rows I send to each peer
+        M = torch.empty(W * W, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(M, mine, group=self.group)
+        M = M.view(W, W).tolist()                                           # M[s][r]: s sends r
+        cut = cut.tolist()
+        rows = local.index_select(0, self.send_idx.index_select(0, nz))     # packed non-zero rows
+        pos = (nz - off[:-1].repeat_interleave(mine)).to(torch.int32)       # position in the request
+        sends, recvs, landed = [], [], []
+        for k in range(1, W):
+            p = (self.rank + k) % W
+            sends += [(pos[cut[p]:cut[p + 1]], p), (rows[cut[p]:cut[p + 1]], p)]
+        for k in range(1, W):
+            r = (self.rank - k) % W
+            c = M[r][self.rank]
+            rp = torch.empty(c, dtype=torch.int32, device=dev)
+            rr = torch.empty((c, F), dtype=local.dtype, device=dev)
+            recvs += [(rp, r), (rr, r)]
+            landed.append((r, rp, rr))
+        _p2p_round(sends, recvs, self.group)
+        for r, rp, rr in landed:
+            if rp.numel():
+                halo.index_copy_(0, rp.to(torch.int64) + self.halo_off[r], rr)
+        self.last_sparse_rows = (int(nz.numel()), self.n_send)              # sent / dense (stats)
+        return halo
+
 
 class ShardedGraph:
     """Rank-local view of Â: the row block of Â and of Âᵀ, both with columns remapped to the
     padded all-gather layout.  Accepted as `adj` by GraphConvolution.forward."""
 
     def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
-                 graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias, **plan_kw):
+                 graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias,
+                 sparse_grad_exchange=True, **plan_kw):
         if exchange not in ("halo", "allgather"):
             raise RuntimeError("exchange must be 'halo' or 'allgather'")
+        # backward exchanges send only the non-zero gradient rows (halo mode; must be set
+        # identically on every rank: it selects the message protocol)
+        self.sparse_grad_exchange = bool(sparse_grad_exchange) and exchange == "halo"
         self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
         self.exchange_mode = exchange
         self.n_global = bounds[-1]
@@ -259,11 +308,16 @@ class ShardedGraph:
             ev[1].record()
             self.timing.append((tag, ev[0], ev[1]))
 
-    def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0):
+    def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0,
+                row_nonzero=None):
+        """Exchange + local product.  `row_nonzero` (callable idx -> bool, see
+        HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel."""
         ev = self._tic(local)
         kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
         if self.exchange_mode == "halo":
-            halo = (self.halo_t if transpose else self.halo).exchange(local)
+            h = self.halo_t if transpose else self.halo
+            halo = h.exchange_sparse(local, row_nonzero) if row_nonzero is not None else \
+                h.exchange(local)
             # dense operand = [own rows (in place) ; halo rows]
             out = self._spmm(self.At if transpose else self.A, local, bias=bias, relu=relu,
                              tag="bwd_local" if transpose else "fwd_local", B2=halo, **kw)
@@ -306,12 +360,23 @@ class ShardedSpMMFunction(torch.autograd.Function):
         grad_support = None
         out = ctx.saved_tensors[0] if ctx.relu else None
         # grad_bias is this rank's partial sum: summed over ranks by allreduce_grads
-        # (the row-sparsity hint is not used here: the operand of the local product is the
-        #  exchanged buffer, whose halo rows carry no flags)
-        grad_out, grad_bias, _ = ctx.sg._bwd(grad_out, out, ctx.relu, ctx.scale,
-                                             ctx.has_bias and ctx.needs_input_grad[2])
+        sg = ctx.sg
+        grad_out, grad_bias, hint = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
+                                            ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
-            grad_support = ctx.sg.product(grad_out.contiguous(), transpose=True)
+            grad_out = grad_out.contiguous()
+            row_nonzero = None
+            if sg.sparse_grad_exchange:
+                # gradients of a loss on few labelled vertices: most rows are zero and need not
+                # travel.  The fused backward pass already produced the row bitmap; without it
+                # (shapes outside that kernel) the flags are computed here
+                if hint is not None:
+                    bits = hint[0]
+                    row_nonzero = lambda idx: ((bits[idx >> 5] >> (idx & 31).to(torch.int32)) & 1).bool()
+                else:
+                    flags = (grad_out != 0).any(1)
+                    row_nonzero = lambda idx: flags[idx]
+            grad_support = sg.product(grad_out, transpose=True, row_nonzero=row_nonzero)
         return None, grad_support, grad_bias, None, None, None
 
 

@@ -53,7 +53,15 @@ def _cpu_bwd(grad_out, out, relu, scale, want_bias):
     return grad_out, (grad_out.sum(0) if want_bias else None), None
 
 
-def _worker(rank, world, port, n, n_edges, out_dir, exchange):
+def _cpu_bwd_with_hint(grad_out, out, relu, scale, want_bias):
+    """Same, plus the row bitmap / count the HIP pass produces (pygcn_amd.spmm.row_bitmap is pure
+    torch), so the bitmap branch of the row-sparse gradient exchange runs on CPU too."""
+    from pygcn_amd.spmm import row_bitmap
+    g, gb, _ = _cpu_bwd(grad_out, out, relu, scale, want_bias)
+    return g, gb, (row_bitmap(g) if g.shape[0] else None)
+
+
+def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -69,7 +77,7 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")   # same on every rank
         sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, exchange=exchange,
                                           graph_factory=_CpuGraph, spmm_fn=_cpu_spmm,
-                                          bwd_fn=_cpu_bwd)
+                                          bwd_fn=_cpu_bwd_with_hint if bitmap_hint else _cpu_bwd)
         recv, full = sg.exchange_rows()
         assert recv <= full and (exchange == "allgather") == (recv == full and sg.halo is None)
         assert sg.bounds[0] == 0 and sg.bounds[-1] == n and sg.n_local == sg.r1 - sg.r0
@@ -107,6 +115,9 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         # features is noticed; an input that requires grad takes the general (exchanging) path and
         # gives the same parameter gradients
         if exchange == "halo":
+            # the layer-2 gradient rows travelled sparsely: only rows of the n/5 labelled vertices
+            sent, dense = sg.halo_t.last_sparse_rows
+            assert sg.sparse_grad_exchange and sent <= dense and (dense == 0 or sent < 0.5 * dense)
             assert sg.n_const_exchanges == 1 and sg.is_constant_input(x_loc)
             first = {k: v.grad.clone() for k, v in model.named_parameters()}
             model.zero_grad()
@@ -146,6 +157,14 @@ def test_sharded_gcn_matches_unsharded_oracle(world, exchange, tmp_path, oracle)
     mp.spawn(_worker, args=(world, port, 4000, 30000, str(tmp_path), exchange), nprocs=world,
              join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_sparse_gradient_exchange_with_bitmap_hint(tmp_path, oracle):
+    """The backward exchange driven by the row bitmap of the fused backward pass (3 ranks)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(3, _free_port(), 4000, 30000, str(tmp_path), "halo", True), nprocs=3,
+             join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2"]
 
 
 def test_partition_and_remap_are_consistent():
@@ -204,6 +223,16 @@ def _halo_worker(rank, world, port, out_dir):
         assert torch.equal(got, table[col.long()]), (rank, got, table[col.long()])
         expect_halo = {0: 0, 1: 0, 2: 4, 3: 1}[rank]      # distinct remote rows referenced
         assert h.n_halo == expect_halo
+        # row-sparse variant: same buffer as the dense exchange for every zero pattern, including
+        # all rows zero and no row zero (zero-length messages on both sides)
+        for pattern in (lambda r: r % 3 == 0, lambda r: True, lambda r: False, lambda r: r in (0, 19)):
+            t2 = table.clone()
+            for r in range(n):
+                if pattern(r):
+                    t2[r] = 0
+            loc2 = t2[bounds[rank]:bounds[rank + 1]].contiguous()
+            flags = (loc2 != 0).any(1)
+            assert torch.equal(h.exchange_sparse(loc2, lambda idx: flags[idx]), h.exchange(loc2))
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
