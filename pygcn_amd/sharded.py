@@ -32,6 +32,10 @@ same layer (reference pygcn/layers.py:32-38):
         backward  grad_W partial = (Â_r · [X_r ; X_halo])ᵀ · grad_pre_r      (summed by the gradient
                                                            all-reduce; X needs no gradient)
     so a 2-layer GCN epoch has 2 exchanges (layer 2 forward / backward) instead of 4.
+  * Backward exchanges are row-sparse (`HaloExchange.exchange_sparse`): the operand is the masked
+    gradient, non-zero on the labelled vertices' rows only; only those rows travel (with their
+    positions in the peer's request list), and their flags + the rank's own become the operand
+    hint of the local transpose product.
 
 The local product is `pygcn_amd.spmm.spmm_csr` (HIP) and the local backward pass
 `pygcn_amd.spmm._grad_pre_and_bias` (HIP).  `graph_factory` / `spmm_fn` / `bwd_fn` exist so the
@@ -44,7 +48,8 @@ import torch
 import torch.distributed as dist
 
 from .graph import CSRGraph
-from .spmm import _dense_forward, _grad_pre_and_bias, _weight_grad, spmm_csr
+from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, pack_row_flags, spmm_csr,
+                   unpack_row_flags)
 
 
 def partition_rows(rowptr, world):
@@ -183,6 +188,7 @@ class HaloExchange:
         only host synchronisation); every rank must call this together, like exchange()."""
         F, dev, W = local.shape[1], local.device, self.world
         halo = torch.zeros((self.n_halo, F), dtype=local.dtype, device=dev)
+        self.last_halo_nonzero = torch.zeros(self.n_halo, dtype=torch.bool, device=dev)
         if W == 1:
             return halo
         keep = row_nonzero(self.send_idx)                                   # [n_send] bool
@@ -208,9 +214,12 @@ class HaloExchange:
             recvs += [(rp, r), (rr, r)]
             landed.append((r, rp, rr))
         _p2p_round(sends, recvs, self.group)
+        self.last_halo_nonzero = torch.zeros(self.n_halo, dtype=torch.bool, device=dev)
         for r, rp, rr in landed:
             if rp.numel():
-                halo.index_copy_(0, rp.to(torch.int64) + self.halo_off[r], rr)
+                dst = rp.to(torch.int64) + self.halo_off[r]
+                halo.index_copy_(0, dst, rr)
+                self.last_halo_nonzero[dst] = True
         self.last_sparse_rows = (int(nz.numel()), self.n_send)              # sent / dense (stats)
         return halo
 
@@ -227,6 +236,7 @@ class ShardedGraph:
         # backward exchanges send only the non-zero gradient rows (halo mode; must be set
         # identically on every rank: it selects the message protocol)
         self.sparse_grad_exchange = bool(sparse_grad_exchange) and exchange == "halo"
+        self._hinted_product = spmm_fn is spmm_csr     # test stand-ins take no operand hint
         self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
         self.exchange_mode = exchange
         self.n_global = bounds[-1]
@@ -309,15 +319,19 @@ class ShardedGraph:
             self.timing.append((tag, ev[0], ev[1]))
 
     def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0,
-                row_nonzero=None):
+                row_nonzero=None, own_flags=None):
         """Exchange + local product.  `row_nonzero` (callable idx -> bool, see
-        HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel."""
+        HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel;
+        with `own_flags` (bool [n_local], the same information for all own rows) the local product
+        also gets the operand hint [own flags | flags of the received rows] and skips zero rows."""
         ev = self._tic(local)
         kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
         if self.exchange_mode == "halo":
             h = self.halo_t if transpose else self.halo
             halo = h.exchange_sparse(local, row_nonzero) if row_nonzero is not None else \
                 h.exchange(local)
+            if row_nonzero is not None and own_flags is not None and self._hinted_product:
+                kw["b_hint"] = pack_row_flags(torch.cat([own_flags, h.last_halo_nonzero]))
             # dense operand = [own rows (in place) ; halo rows]
             out = self._spmm(self.At if transpose else self.A, local, bias=bias, relu=relu,
                              tag="bwd_local" if transpose else "fwd_local", B2=halo, **kw)
@@ -365,18 +379,16 @@ class ShardedSpMMFunction(torch.autograd.Function):
                                             ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             grad_out = grad_out.contiguous()
-            row_nonzero = None
+            row_nonzero = flags = None
             if sg.sparse_grad_exchange:
                 # gradients of a loss on few labelled vertices: most rows are zero and need not
                 # travel.  The fused backward pass already produced the row bitmap; without it
                 # (shapes outside that kernel) the flags are computed here
-                if hint is not None:
-                    bits = hint[0]
-                    row_nonzero = lambda idx: ((bits[idx >> 5] >> (idx & 31).to(torch.int32)) & 1).bool()
-                else:
-                    flags = (grad_out != 0).any(1)
-                    row_nonzero = lambda idx: flags[idx]
-            grad_support = sg.product(grad_out, transpose=True, row_nonzero=row_nonzero)
+                flags = unpack_row_flags(hint[0], grad_out.shape[0]) if hint is not None else \
+                    (grad_out != 0).any(1)
+                row_nonzero = lambda idx: flags[idx]
+            grad_support = sg.product(grad_out, transpose=True, row_nonzero=row_nonzero,
+                                      own_flags=flags if row_nonzero is not None else None)
         return None, grad_support, grad_bias, None, None, None
 
 

@@ -179,10 +179,8 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False):
     return grad_pre, colsum.to(grad_out.dtype), hint
 
 
-def row_bitmap(B):
-    """(bitmap, count) hint for a dense operand: bit r set iff row r of B has a non-zero element
-    (torch ops; the backward pass gets the same thing for free from backward_with_colsum)."""
-    nz = (B != 0).any(1)
+def pack_row_flags(nz):
+    """bool [n] -> the operand hint (bitmap int32 [ceil(n/32)], count int32 [1]); torch ops."""
     n = nz.numel()
     pad = (-n) % 32
     if pad:
@@ -190,6 +188,18 @@ def row_bitmap(B):
     w = (nz.view(-1, 32).to(torch.int64) << torch.arange(32, device=nz.device)).sum(1)
     w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
     return w, nz.sum().to(torch.int32).reshape(1)
+
+
+def unpack_row_flags(bits, n):
+    """Inverse of pack_row_flags: bitmap int32 -> bool [n]."""
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32)
+    return ((bits[:, None] >> sh) & 1).bool().reshape(-1)[:n]
+
+
+def row_bitmap(B):
+    """(bitmap, count) hint for a dense operand: bit r set iff row r of B has a non-zero element
+    (torch ops; the backward pass gets the same thing for free from backward_with_colsum)."""
+    return pack_row_flags((B != 0).any(1))
 
 
 def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False):
