@@ -347,10 +347,12 @@ def main():
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
-            "spmm_bwd_note": ("the transpose products skip all-zero rows of their dense operand "
-                              "(gradients of the idx_train loss: 5 % of the rows non-zero at layer 2, "
-                              "16 % at layer 1); `value` and `roofline` are the forward product, "
-                              "whose operand is dense") if world == 1 else
+            "spmm_bwd_note": ("layer 2: transpose product that skips the all-zero rows of its dense "
+                              "operand (gradients of the idx_train loss: 5 % of the rows non-zero); "
+                              "layer 1 (input needs no gradient): grad_W = (A x X)^T x grad_pre from a "
+                              "forward product restricted to the 16 % of the rows that meet a "
+                              "non-zero row of grad_pre (80 % of the stored entries); `value` and "
+                              "`roofline` are the unrestricted forward product") if world == 1 else
                              "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),

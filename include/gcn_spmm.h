@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 9
+#define GCN_ABI_VERSION 10
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -170,6 +170,13 @@ typedef struct gcn_epilogue {
      * when it runs, not when it is enqueued, so a launch captured into a hipGraph draws a fresh
      * mask on every replay if the graph also updates *seed_dev (e.g. a captured increment). */
     const uint64_t *seed_dev;
+    /* Optional bitmap over the OUTPUT rows (NULL = all rows wanted): rows whose bit in
+     * c_row_select[ceil(n_rows/32)] is clear are not needed by the caller — the kernel may skip
+     * their stored entries and leave those rows of C unwritten (contents undefined).  Lets
+     * grad_W = (A·X)^T · grad of a first layer be formed from the rows of A·X that meet a non-zero
+     * row of grad only (the bitmap gcn_relu_dropout_backward_colsum already produced).  Honoured
+     * by the wide kernel (rows of >= 528 bytes); narrower shapes compute every row. */
+    const uint32_t *c_row_select;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

@@ -88,6 +88,7 @@ struct KParams {
     uint8_t *cflag;          // optional output [n_rows], pre-zeroed: 1 = stored row has a non-zero
     int32_t log_softmax;     // store log_softmax of the row (whole row inside one store_out call)
     const uint64_t *seed_dev;   // optional device-resident dropout seed (overrides seed_lo/hi)
+    const uint32_t *csel;       // optional bitmap over output rows: clear bit = row not wanted
 };
 
 // ------------------------------------------------------------------------------------------
@@ -306,10 +307,17 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     int rend = ROWS ? readlane_i(rel_end, 0) : INT_MAX;
     const bool flags = FLAGS && use_row_flags(p, 3, 4);   // wave-uniform; FLAGS = false: dense operand,
                                                     // the flag code is compiled out
+    const bool sel = FLAGS && ROWS && p.csel != nullptr;  // output-row selection (wave-uniform)
+    // lane l < nr: is row row0 + l wanted
+    const int want = (sel && lane < nr) ? (int)row_bit(p.csel, (int)row0 + lane) : 1;
+    auto emit = [&](int rr) {   // store row rr of the item unless the caller does not want it
+        if (!sel || readlane_i(want, rr))
+            store_out<T, VEC, kWave, XEPI>(p, row0 + rr, f, act, acc, bias);
+    };
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
             while (e >= rend) {   // row finished (loop: rows without stored entries follow)
-                store_out<T, VEC, kWave, XEPI>(p, row0 + r, f, act, acc, bias);
+                emit(r);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
                 ++r;
@@ -332,11 +340,29 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
         }
         // row-sparse operand: one byte gather per tile tells which of the 64 rows are all-zero;
         // their slots get num_records = 0 like the slots past the end of the tile (no traffic)
-        if (FLAGS && flags) {
+        if (FLAGS && (flags || sel)) {
             // row-sparse operand: one bitmap probe per lane tells which of the tile's rows of B are
             // all-zero; only the stored entries whose bit is set are visited (ascending order, so
             // the row bookkeeping of consume() is unchanged), D at a time
-            const int fv = (lane < cnt) ? (int)row_bit(p.bflag, cv) : 0;
+            int fv = (lane < cnt) ? 1 : 0;
+            if (flags) fv = fv && row_bit(p.bflag, cv);
+            if (sel) {
+                // output-row selection: the row of entry i = t + lane is the first r with
+                // rel_end[r] > i (binary search over the row ends held in lanes 0..nr-1); entries
+                // of rows the caller does not want are not visited either
+                const int i = t + lane;
+                int lo = 0, hi = nr - 1;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = __shfl(rel_end, mid, kWave);
+                    if (v > i) hi = mid; else lo = min(mid + 1, nr - 1);
+                }
+                // (the shuffle must run in ALL lanes: a lane switched off by a short-circuit would
+                //  supply 0 to the lanes that read it)
+                const int w = __shfl(want, lo, kWave);
+                fv &= w;
+            }
             unsigned long long m = __ballot(fv != 0);
             while (m) {
                 int kk[D];
@@ -370,7 +396,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
     if (ROWS) {
         while (r < nr) {   // last row of the item and any trailing empty rows
-            store_out<T, VEC, kWave, XEPI>(p, row0 + r, f, act, acc, bias);
+            emit(r);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             ++r;
@@ -401,6 +427,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
     if (item < p.n_chunks) {
         // ---- one chunk of a long row -> fp32 partial slab
         const int row = p.chunk_row[item];
+        if (FLAGS && p.csel != nullptr && !row_bit(p.csel, row)) return;   // long row not wanted
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
         wide_stream<T, VEC, D, false, FLAGS, XEPI>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
@@ -701,6 +728,7 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
     const int j = blockIdx.x;
     if (j >= p.n_long) return;
     const int64_t row = p.long_row[j];
+    if (p.csel != nullptr && !row_bit(p.csel, (int)row)) return;   // (its chunks were skipped too)
     const int c0 = p.long_chunk0[j], c1 = p.long_chunk0[j + 1];
     if (p.log_softmax) {
         // F <= 512 (host check): thread t owns columns t and t + 256; block-wide max and sum
@@ -975,7 +1003,7 @@ void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
     const bool xepi = kp.log_softmax || kp.cflag != nullptr;
 #define GCN_LAUNCH_WIDE(I, FL, X) \
     hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, I, D, FL, X>), grid, block, 0, s, kp)
-    if (kp.bflag != nullptr) {   // row-sparse operand hint: the variant that reads the row flags
+    if (kp.bflag != nullptr || kp.csel != nullptr) {   // operand hint / row selection: the flag variant
         if (xepi) {
             if (is64) GCN_LAUNCH_WIDE(int64_t, true, true);
             else GCN_LAUNCH_WIDE(int32_t, true, true);
@@ -1225,6 +1253,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
     kp.seed_dev = ep ? ep->seed_dev : nullptr;
+    kp.csel = ep ? ep->c_row_select : nullptr;
     kp.B2 = ep ? ep->b2 : nullptr;
     kp.ldb2 = ep && ep->b2 ? ep->ldb2 : 0;
     kp.b_split = (ep && ep->b2) ? (int32_t)std::min<int64_t>(ep->b_split, INT32_MAX) : INT32_MAX;
@@ -1257,6 +1286,7 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.c_row_nonzero = nullptr;
     ep.log_softmax = 0;
     ep.seed_dev = nullptr;
+    ep.c_row_select = nullptr;
     ep.b2 = nullptr;
     ep.ldb2 = 0;
     ep.b_split = 0;

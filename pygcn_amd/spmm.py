@@ -27,7 +27,7 @@ def set_timing_records(records):
 
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
-             b_hint=None, B2=None, c_flags=None, log_softmax=False):
+             b_hint=None, B2=None, c_flags=None, log_softmax=False, c_select=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
@@ -39,6 +39,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     stored row r has a non-zero element (gcn_epilogue.c_row_nonzero).
     `log_softmax`: store log_softmax over each row of A·B + bias (`F.log_softmax(x, dim=1)`, the
     reference model's last line) — see log_softmax_fusable() for the shapes that allow it.
+    `c_select`: optional int32 bitmap [ceil(n_rows/32)] over the OUTPUT rows: rows whose bit is
+    clear are not wanted and may be left unwritten (gcn_epilogue.c_row_select).
     `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
     (hipGraph replays draw a fresh mask if the graph updates the tensor, see dropout_seed_for)."""
     if not isinstance(graph, CSRGraph):
@@ -66,6 +68,10 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     if c_flags is not None and (c_flags.dtype != torch.uint8 or c_flags.numel() != n_rows
                                 or not c_flags.is_contiguous() or c_flags.device != B.device):
         raise RuntimeError("spmm_csr: c_flags must be a contiguous uint8 [n_rows] device tensor")
+    if c_select is not None and (c_select.dtype != torch.int32 or c_select.device != B.device
+                                 or c_select.numel() != (n_rows + 31) // 32
+                                 or not c_select.is_contiguous()):
+        raise RuntimeError("spmm_csr: c_select must be a contiguous int32 bitmap [ceil(n_rows/32)]")
     if n_rows == 0 or F == 0:
         return out
     if bias is not None:
@@ -96,7 +102,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  B2.stride(0) if B2 is not None and B2.numel() else 0,
                                  B.shape[0] if B2 is not None else 0,
                                  c_flags.data_ptr() if c_flags is not None else None,
-                                 int(bool(log_softmax)), seed_dev)
+                                 int(bool(log_softmax)), seed_dev,
+                                 c_select.data_ptr() if c_select is not None else None)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -247,8 +254,10 @@ def dropout_seed_for(tensor):
         if capturing:
             raise RuntimeError("run one training step with dropout before capturing it into a "
                                "hipGraph (the device-resident dropout seed is created on first use)")
-        t = _device_seeds[key] = torch.full((1,), next_dropout_seed(), dtype=torch.int64,
-                                            device=tensor.device)
+        # start value: the default generator's seed (torch.manual_seed), read without advancing
+        # the generator — creating the tensor must not shift the stream of host seeds
+        t = _device_seeds[key] = torch.full((1,), torch.initial_seed() & (2 ** 63 - 1),
+                                            dtype=torch.int64, device=tensor.device)
     if not capturing:
         return next_dropout_seed()
     t.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment, wraps; recorded in the capture
@@ -441,9 +450,20 @@ class GraphConvFunction(torch.autograd.Function):
         graph_t = ctx.graph.t()
         n = graph_t.shape[0]
         c_flags = rows = None
-        if (hint is not None and _row_compaction and n >= MIN_ROWS
-                and not torch.cuda.is_current_stream_capturing()
-                and int(hint[1].item()) * 8 < grad_pre.shape[0]):
+        compact = (hint is not None and _row_compaction and n >= MIN_ROWS
+                   and not torch.cuda.is_current_stream_capturing())
+        nz_rows = int(hint[1].item()) if compact else None
+        if compact and not need_in and nz_rows * 3 < grad_pre.shape[0]:
+            # First layer (its input needs no gradient) under a row-sparse grad_pre:
+            #     grad_W = inputᵀ · (Aᵀ · grad_pre) = (A · input)ᵀ · grad_pre,
+            # and only the rows of A · input that meet a non-zero row of grad_pre take part: a
+            # forward product restricted to those rows (c_select = the bitmap of grad_pre) and a
+            # GEMM over them replace the transpose product and the full-height GEMM
+            z = spmm_csr(ctx.graph, input, tag="bwd", c_select=hint[0])
+            rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
+            grad_w = _weight_grad(z.index_select(0, rows), grad_pre.index_select(0, rows))
+            return None, grad_w, grad_bias, None, None, None, None, None
+        if compact and nz_rows * 8 < grad_pre.shape[0]:
             c_flags = torch.zeros(n, dtype=torch.uint8, device=grad_pre.device)
         grad_sup = spmm_csr(graph_t, grad_pre.contiguous(), tag="bwd", b_hint=hint, c_flags=c_flags)
         if c_flags is not None:

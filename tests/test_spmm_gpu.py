@@ -934,3 +934,83 @@ def test_randomized_option_combinations(oracle, dev):
         assert err <= (2.0 ** -7 if bf16 else 1e-5) * scale, f"{what}: err {err:.3e} scale {scale:.3e}"
         if use_flags:
             assert torch.equal(flags.bool(), (out != 0).any(1)), what
+
+
+@pytest.mark.parametrize("F,dtype,idx64", [(256, torch.float32, False), (600, torch.float32, True),
+                                           (512, torch.bfloat16, False), (64, torch.float32, False)])
+@pytest.mark.parametrize("density", [0.0, 0.1, 0.6, 1.0])
+def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
+    """gcn_epilogue.c_row_select: rows whose bit is set equal the unrestricted product (bitwise
+    in the wide kernel: same entries, same order); the other rows may hold anything and are not
+    looked at.  Long rows (chunk slab + reduce), empty rows, rows around the tile boundary and
+    the combination with the operand hint and the output flags are all in the case; F = 64 takes
+    the narrow kernel, which computes every row."""
+    from pygcn_amd import spmm_csr
+    from pygcn_amd.spmm import pack_row_flags, row_bitmap
+    a = _skewed_csr(oracle, 2500, 2200, 6, seed=F + 31, empties=100,
+                    hubs=((3, 1200), (900, 300), (901, 40), (1700, 64), (1701, 65), (1702, 63)))
+    rp = a.rowptr.astype(np.int64 if idx64 else np.int32)
+    from pygcn_amd import CSRGraph
+    g = CSRGraph(torch.from_numpy(rp).to(dev), torch.from_numpy(a.col).to(dev),
+                 torch.from_numpy(a.val).to(dev), a.shape)
+    gen = torch.Generator(device=dev).manual_seed(F)
+    B = torch.randn(2200, F, generator=gen, device=dev).to(dtype)
+    want = torch.rand(2500, generator=gen, device=dev) < density
+    if 0.0 < density < 1.0:
+        want[3], want[900], want[1701] = True, False, True       # one long row in, one out
+    bits, _ = pack_row_flags(want)
+    full = spmm_csr(g, B)
+    out = torch.full((2500, F), float("nan"), device=dev).to(dtype)
+    spmm_csr(g, B, out=out, c_select=bits)
+    assert torch.equal(out[want], full[want])
+    if F >= 256 and density < 1.0:     # wide kernel: unwanted rows were really skipped
+        assert bool(out[~want].isnan().all())
+    # together with a row-sparse operand and the output flags
+    Bs = B * (torch.rand(2200, 1, generator=gen, device=dev) < 0.1)
+    flags = torch.zeros(2500, dtype=torch.uint8, device=dev)
+    out2 = torch.zeros((2500, F), device=dev).to(dtype)
+    spmm_csr(g, Bs, out=out2, c_select=bits, b_hint=row_bitmap(Bs), c_flags=flags)
+    ref2 = spmm_csr(g, Bs)
+    assert_normwise(out2[want].float().cpu(), ref2[want].float().cpu().numpy(), 1e-6, "select + hint")
+    assert torch.equal(flags.bool()[want], (ref2 != 0).any(1)[want])
+    with pytest.raises(RuntimeError, match="c_select"):
+        spmm_csr(g, B, c_select=bits[:-1])
+
+
+def test_first_layer_weight_gradient_through_row_selected_product(oracle, dev):
+    """With a row-sparse grad_pre the first layer forms grad_W = (A·X)ᵀ·grad_pre from a
+    row-selected forward product; same gradients as the transpose-product path."""
+    import importlib
+    from pygcn_amd import CSRGraph, GraphConvolution
+    from pygcn_amd.utils import rmat_graph
+    S = importlib.import_module("pygcn_amd.spmm")
+    n = 1 << 18
+    rowptr, col, val = rmat_graph(n, 4 * n, seed=6, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    torch.manual_seed(0)
+    layer = GraphConvolution(256, 256).to(dev)
+    x = torch.randn(n, 256, device=dev)
+    idx = torch.randperm(n, device=dev)[: n // 20]
+    tgt = torch.randn(idx.numel(), 256, device=dev)
+
+    def grads(compaction):
+        S.set_row_compaction(compaction)
+        try:
+            layer.zero_grad()
+            seen = []
+            orig = S.spmm_csr
+            S.spmm_csr = lambda *a_, **k: (seen.append(k.get("c_select") is not None), orig(*a_, **k))[1]
+            try:
+                torch.manual_seed(1)
+                ((layer(x, g, relu=True)[idx] - tgt) ** 2).sum().backward()
+            finally:
+                S.spmm_csr = orig
+            return [p.grad.clone() for p in layer.parameters()], any(seen)
+        finally:
+            S.set_row_compaction(True)
+
+    sel, used = grads(True)
+    ref, used_ref = grads(False)
+    assert used and not used_ref
+    for a_, b_ in zip(sel, ref):
+        assert_normwise(a_.cpu(), b_.cpu().numpy(), TOL, "row-selected grad_W")
