@@ -426,14 +426,25 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         sg = ctx.sg
         x_local, x_halo = ctx.saved_tensors[:2]
         out = ctx.saved_tensors[3] if ctx.relu else None
-        grad_pre, grad_bias, _ = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
-                                         ctx.has_bias and ctx.needs_input_grad[4])
+        grad_pre, grad_bias, hint = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
+                                            ctx.has_bias and ctx.needs_input_grad[4])
         grad_w = None
         if ctx.needs_input_grad[3]:
+            grad_pre = grad_pre.contiguous()
+            # rows of Â_r · X that meet an all-zero row of grad_pre add nothing: with the bitmap
+            # of the fused backward pass the product computes only the others (c_select) and the
+            # GEMM runs over them (a purely local decision: no collective depends on it)
+            sparse = (hint is not None and sg._hinted_product
+                      and int(hint[1].item()) * 3 < grad_pre.shape[0])
             ev = sg._tic(grad_pre)
-            z = sg._spmm(sg.A, x_local, tag="bwd_local", B2=x_halo)   # this rank's rows of Â · X
+            z = sg._spmm(sg.A, x_local, tag="bwd_local", B2=x_halo,   # this rank's rows of Â · X
+                         **({"c_select": hint[0]} if sparse else {}))
             sg._toc(ev, "bwd")
-            grad_w = _weight_grad(z, grad_pre.contiguous())
+            if sparse:
+                rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
+                grad_w = _weight_grad(z.index_select(0, rows), grad_pre.index_select(0, rows))
+            else:
+                grad_w = _weight_grad(z, grad_pre)
         return None, None, None, grad_w, grad_bias, None, None, None
 
 
