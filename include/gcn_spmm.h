@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 10
+#define GCN_ABI_VERSION 11
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -177,6 +177,10 @@ typedef struct gcn_epilogue {
      * row of grad only (the bitmap gcn_relu_dropout_backward_colsum already produced).  Honoured
      * by the wide kernel (rows of >= 528 bytes); narrower shapes compute every row. */
     const uint32_t *c_row_select;
+    /* With c_row_nonzero: rows of the result that are entirely zero are NOT stored (their flag
+     * stays 0, their memory is left untouched) — for a consumer that reads the flagged rows only.
+     * Rows longer than the plan's long_thresh are always stored. */
+    int32_t c_skip_zero_rows;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 10
+GCN_ABI_VERSION = 11
 GCN_DEFAULT_ITEM_COST = 64
 GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
@@ -41,7 +41,8 @@ class GcnEpilogue(ctypes.Structure):
                 ("b_row_nonzero", ctypes.c_void_p), ("b_nnz_rows", ctypes.c_void_p),
                 ("b2", ctypes.c_void_p), ("ldb2", ctypes.c_int64), ("b_split", ctypes.c_int64),
                 ("c_row_nonzero", ctypes.c_void_p), ("log_softmax", ctypes.c_int32),
-                ("seed_dev", ctypes.c_void_p), ("c_row_select", ctypes.c_void_p)]
+                ("seed_dev", ctypes.c_void_p), ("c_row_select", ctypes.c_void_p),
+                ("c_skip_zero_rows", ctypes.c_int32)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)

@@ -89,6 +89,7 @@ struct KParams {
     int32_t log_softmax;     // store log_softmax of the row (whole row inside one store_out call)
     const uint64_t *seed_dev;   // optional device-resident dropout seed (overrides seed_lo/hi)
     const uint32_t *csel;       // optional bitmap over output rows: clear bit = row not wanted
+    int32_t cskip;              // with cflag: all-zero rows are not stored
 };
 
 // ------------------------------------------------------------------------------------------
@@ -229,7 +230,7 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
 // (a row is held by LPR consecutive lanes, VEC elements each, starting at a multiple of LPR)
 // XEPI = false compiles the log_softmax / output-row-flag code out: the plain instantiations keep
 // the register budget they were tuned with (wide fp32: 62 VGPRs; the extras cost 8-15 more)
-template <typename T, int VEC, int LPR, bool XEPI>
+template <typename T, int VEC, int LPR, bool XEPI, bool ALLOW_SKIP = true>
 __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
                                           const float (&acc)[VEC], const float (&bias)[VEC])
 {
@@ -256,15 +257,25 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o[i] -= lse;
     }
-    if (act) {
-        T *dst = (T *)p.C + row * p.ldc + f;
-        *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
-    }
+    bool do_store = act;
     if (XEPI && p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) nz |= (o[i] != 0.f);
+        if (ALLOW_SKIP && p.cskip) {
+            // an all-zero row is not written at all: the decision must be the same for the LPR
+            // lanes that hold the row -> their slice of the wave's ballot
+            const unsigned long long b = __ballot(act && nz);
+            const int ln = (int)(threadIdx.x & (kWave - 1));
+            const unsigned long long gm =
+                LPR >= kWave ? ~0ull : (((1ull << LPR) - 1ull) << (ln & ~(LPR - 1)));
+            do_store = act && (b & gm) != 0ull;
+        }
         if (act && nz) p.cflag[row] = 1;
+    }
+    if (do_store) {
+        T *dst = (T *)p.C + row * p.ldc + f;
+        *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
     }
 }
 
@@ -775,7 +786,7 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
         for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
-        store_out<T, 1, 1, true>(p, row, f, true, a, b);
+        store_out<T, 1, 1, true, false>(p, row, f, true, a, b);   // long rows: always stored
     }
 }
 
@@ -1042,6 +1053,8 @@ int spmm_typed(const gcn_csr_plan *plan, KParams &kp, hipStream_t s)
                         ((kp.ldb * (int64_t)sizeof(T)) % 16 == 0) &&
                         ((kp.ldc * (int64_t)sizeof(T)) % 16 == 0);
     const unsigned nblk = (unsigned)((kp.n_total + kWavesPerBlock - 1) / kWavesPerBlock);
+    // skipping all-zero rows is a per-store decision: only when one store call holds the whole row
+    if (kp.cskip && !(F <= kWave || (vec_ok && F / VECW <= kWave))) kp.cskip = 0;
     if (kp.log_softmax && !(F <= kWave || (vec_ok && F / VECW <= kWave)))
         return fail(GCN_E_BADARG, "gcn_spmm_csr_ep: log_softmax needs the row inside one wavefront "
                                   "(F <= 64, or 16-byte aligned operands with F/lane width <= 64)");
@@ -1254,6 +1267,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
     kp.seed_dev = ep ? ep->seed_dev : nullptr;
     kp.csel = ep ? ep->c_row_select : nullptr;
+    kp.cskip = (ep && ep->c_skip_zero_rows && ep->c_row_nonzero) ? 1 : 0;
     kp.B2 = ep ? ep->b2 : nullptr;
     kp.ldb2 = ep && ep->b2 ? ep->ldb2 : 0;
     kp.b_split = (ep && ep->b2) ? (int32_t)std::min<int64_t>(ep->b_split, INT32_MAX) : INT32_MAX;
@@ -1287,6 +1301,7 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
     ep.log_softmax = 0;
     ep.seed_dev = nullptr;
     ep.c_row_select = nullptr;
+    ep.c_skip_zero_rows = 0;
     ep.b2 = nullptr;
     ep.ldb2 = 0;
     ep.b_split = 0;

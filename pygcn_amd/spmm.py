@@ -27,7 +27,8 @@ def set_timing_records(records):
 
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
-             b_hint=None, B2=None, c_flags=None, log_softmax=False, c_select=None):
+             b_hint=None, B2=None, c_flags=None, log_softmax=False, c_select=None,
+             skip_zero_rows=False):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
@@ -39,6 +40,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     stored row r has a non-zero element (gcn_epilogue.c_row_nonzero).
     `log_softmax`: store log_softmax over each row of A·B + bias (`F.log_softmax(x, dim=1)`, the
     reference model's last line) — see log_softmax_fusable() for the shapes that allow it.
+    `skip_zero_rows` (with c_flags): rows of the result that are entirely zero are not stored at
+    all — only the flagged rows of the returned tensor are defined.
     `c_select`: optional int32 bitmap [ceil(n_rows/32)] over the OUTPUT rows: rows whose bit is
     clear are not wanted and may be left unwritten (gcn_epilogue.c_row_select).
     `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
@@ -103,7 +106,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  B.shape[0] if B2 is not None else 0,
                                  c_flags.data_ptr() if c_flags is not None else None,
                                  int(bool(log_softmax)), seed_dev,
-                                 c_select.data_ptr() if c_select is not None else None)
+                                 c_select.data_ptr() if c_select is not None else None,
+                                 int(bool(skip_zero_rows) and c_flags is not None))
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -465,11 +469,15 @@ class GraphConvFunction(torch.autograd.Function):
             return None, grad_w, grad_bias, None, None, None, None, None
         if compact and nz_rows * 8 < grad_pre.shape[0]:
             c_flags = torch.zeros(n, dtype=torch.uint8, device=grad_pre.device)
-        grad_sup = spmm_csr(graph_t, grad_pre.contiguous(), tag="bwd", b_hint=hint, c_flags=c_flags)
+        # with the flags requested, all-zero rows of the product are not even written: the GEMMs
+        # below read the flagged rows only
+        grad_sup = spmm_csr(graph_t, grad_pre.contiguous(), tag="bwd", b_hint=hint, c_flags=c_flags,
+                            skip_zero_rows=c_flags is not None)
         if c_flags is not None:
             rows = torch.nonzero(c_flags).squeeze(1)
-            if rows.numel() * 3 >= n:
+            if rows.numel() * 3 >= n:     # too dense to pay: make the skipped rows real zeros
                 rows = None
+                grad_sup = torch.where(c_flags.bool()[:, None], grad_sup, torch.zeros_like(grad_sup[:1]))
         grad_in, grad_w = _dense_grads(input, weight, grad_sup, need_in, need_w, rows)
         return grad_in, grad_w, grad_bias, None, None, None, None, None
 

@@ -691,6 +691,16 @@ def test_output_row_flags(oracle, dev, F, dtype):
         assert torch.equal(flags.bool(), expect)
         assert 0 < int(expect.sum()) < 2500                   # the case exercises both outcomes
         assert torch.equal(out, spmm_csr(g, B, b_hint=hint))  # the flags change nothing else
+        # skip mode: all-zero rows are not written at all (long rows excepted: always stored)
+        flags2 = torch.zeros(2500, dtype=torch.uint8, device=dev)
+        out2 = torch.full((2500, F), float("nan"), device=dev).to(dtype)
+        spmm_csr(g, B, b_hint=hint, c_flags=flags2, skip_zero_rows=True, out=out2)
+        assert torch.equal(flags2, flags)
+        assert torch.equal(out2[expect], out[expect])
+        rest = out2[~expect]
+        assert bool((rest.isnan().all(1) | (rest == 0).all(1)).all())
+        if F <= 256 or (dtype == torch.bfloat16 and F <= 512):
+            assert int(rest.isnan().all(1).sum()) >= rest.shape[0] - 3    # all but the long rows
     bias = -torch.rand(F, device=dev) * 0.05                  # negative bias + ReLU: whole rows -> 0
     flags = torch.zeros(2500, dtype=torch.uint8, device=dev)
     out = spmm_csr(g, B, bias=bias, relu=True, c_flags=flags)
