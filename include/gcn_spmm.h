@@ -174,8 +174,7 @@ typedef struct gcn_epilogue {
      * c_row_select[ceil(n_rows/32)] is clear are not needed by the caller — the kernel may skip
      * their stored entries and leave those rows of C unwritten (contents undefined).  Lets
      * grad_W = (A·X)^T · grad of a first layer be formed from the rows of A·X that meet a non-zero
-     * row of grad only (the bitmap gcn_relu_dropout_backward_colsum already produced).  Honoured
-     * by the wide kernel (rows of >= 528 bytes); narrower shapes compute every row. */
+     * row of grad only (the bitmap gcn_relu_dropout_backward_colsum already produced). */
     const uint32_t *c_row_select;
     /* With c_row_nonzero: rows of the result that are entirely zero are NOT stored (their flag
      * stays 0, their memory is left untouched) — for a consumer that reads the flagged rows only.

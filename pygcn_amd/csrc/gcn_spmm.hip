@@ -593,8 +593,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
         bias[i] = 0.f;
     }
 
+    const bool sel = p.csel != nullptr;   // output-row selection (wave-uniform)
     if (item < p.n_chunks) {
         const int row = p.chunk_row[item];
+        if (sel && !row_bit(p.csel, row)) return;   // long row not wanted
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
         narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
@@ -623,6 +625,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
         int64_t e0 = ea;
         for (int r = ra; r < rb; ++r) {
             const int64_t e1 = (int64_t)rp[r + 1];
+            if (sel && !row_bit(p.csel, r)) {   // row not wanted: neither computed nor stored
+                e0 = e1;
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
@@ -659,7 +665,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     }
     const int up = __shfl_up(rel_end, 1, kWave);
     const int rel_start = (lane == 0) ? 0 : up;
-    unsigned long long medium = __ballot(lane < nr && rel_end - rel_start > kShort);
+    // lane r < nr: is row ra + r wanted by the caller (c_row_select)
+    const int wantn = (sel && lane < nr) ? (int)row_bit(p.csel, ra + lane) : 1;
+    unsigned long long medium = __ballot(lane < nr && rel_end - rel_start > kShort && wantn != 0);
 
     for (int q0 = 0; q0 < nr; q0 += G * RU) {
         int e0[RU], e1[RU], row[RU];
@@ -669,7 +677,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
             const int r = q0 + ru * G + g;
             const int s0 = __shfl(rel_start, r & (kWave - 1), kWave);
             const int s1 = __shfl(rel_end, r & (kWave - 1), kWave);
-            const bool mine = r < nr && s1 - s0 <= kShort;
+            const int wr = __shfl(wantn, r & (kWave - 1), kWave);   // (all lanes run the shuffle)
+            const bool mine = r < nr && s1 - s0 <= kShort && wr != 0;
             row[ru] = mine ? r : -1;
             e0[ru] = s0;
             e1[ru] = mine ? s1 : s0;

@@ -947,14 +947,16 @@ def test_randomized_option_combinations(oracle, dev):
 
 
 @pytest.mark.parametrize("F,dtype,idx64", [(256, torch.float32, False), (600, torch.float32, True),
-                                           (512, torch.bfloat16, False), (64, torch.float32, False)])
+                                           (512, torch.bfloat16, False), (64, torch.float32, False),
+                                           (16, torch.float32, True), (7, torch.float32, False),
+                                           (128, torch.bfloat16, False)])
 @pytest.mark.parametrize("density", [0.0, 0.1, 0.6, 1.0])
 def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
     """gcn_epilogue.c_row_select: rows whose bit is set equal the unrestricted product (bitwise
     in the wide kernel: same entries, same order); the other rows may hold anything and are not
     looked at.  Long rows (chunk slab + reduce), empty rows, rows around the tile boundary and
-    the combination with the operand hint and the output flags are all in the case; F = 64 takes
-    the narrow kernel, which computes every row."""
+    the combination with the operand hint and the output flags are all in the case; F = 64 / 16 / 7
+    take the narrow kernel (row-per-lane-group, medium-row and one-row-at-a-time paths)."""
     from pygcn_amd import spmm_csr
     from pygcn_amd.spmm import pack_row_flags, row_bitmap
     a = _skewed_csr(oracle, 2500, 2200, 6, seed=F + 31, empties=100,
@@ -973,7 +975,7 @@ def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
     out = torch.full((2500, F), float("nan"), device=dev).to(dtype)
     spmm_csr(g, B, out=out, c_select=bits)
     assert torch.equal(out[want], full[want])
-    if F >= 256 and density < 1.0:     # wide kernel: unwanted rows were really skipped
+    if density < 1.0:                  # unwanted rows were really skipped (both kernels)
         assert bool(out[~want].isnan().all())
     # together with a row-sparse operand and the output flags
     Bs = B * (torch.rand(2200, 1, generator=gen, device=dev) < 0.1)
