@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 11
+GCN_ABI_VERSION = 12
 GCN_DEFAULT_ITEM_COST = 64
 GCN_DEFAULT_LONG_THRESH = 256
 GCN_DTYPE_F32 = 0
@@ -122,11 +122,13 @@ def lib():
                                                    ctypes.c_void_p,
                                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                                    ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_int,
                                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_log_softmax_backward_colsum.restype = ctypes.c_int
     L.gcn_log_softmax_backward_colsum.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_int,
                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_workspace_bytes.argtypes = []

@@ -19,6 +19,17 @@ _DTYPES = {torch.float32: _native.GCN_DTYPE_F32, torch.bfloat16: _native.GCN_DTY
 # is bracketed by HIP events recorded on the launch stream and (tag, start, end, graph) appended.
 _timing_records = None
 
+# Test switch: tensors whose unflagged rows are deliberately left unwritten (skip_zero_rows,
+# c_select) are pre-filled with NaN instead of being allocated empty, so a consumer that reads a
+# row it must not read shows up as NaN in the gradients (tests/test_spmm_gpu.py).
+_poison_unwritten = False
+
+
+def _maybe_poisoned(shape, dtype, device):
+    if _poison_unwritten:
+        return torch.full(shape, float("nan"), dtype=dtype, device=device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
 
 def set_timing_records(records):
     """Install (or remove, with None) the list that receives per-launch HIP event pairs."""
@@ -144,13 +155,16 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
     return res
 
 
-def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False):
+def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_zero_rows=False):
     """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 / bf16 [N, F]
     tensors (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
     `log_softmax=True`: `out` holds log-probabilities and grad_pre = grad_out - exp(out) *
     rowsum(grad_out) (C-ABI gcn_log_softmax_backward_colsum; rows need F / lane width <= 64).  The
     hint — (row bitmap int32 [ceil(N/32)], nnz_rows int32 [1]) or None when F > 256 — can be handed to
     spmm_csr(b_hint=...) when grad_pre is the dense operand of the following product.
+    `skip_zero_rows=True` (needs `out` and a hint): rows of grad_pre that are entirely zero are
+    NOT written — only the rows whose hint bit is set are defined; for consumers that read those
+    rows only.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
     _require_cuda(grad_out, "grad_out")
@@ -165,25 +179,27 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False):
                                  or grad_out.shape[1] // (16 // grad_out.element_size()) > 64))):
         return None
     n, F = grad_out.shape
-    grad_pre = torch.empty_like(grad_out) if out is not None else grad_out
+    grad_pre = _maybe_poisoned(grad_out.shape, grad_out.dtype, grad_out.device) if out is not None \
+        else grad_out
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
     hint = None
     if F <= (256 if grad_out.dtype == torch.float32 else 512):   # a row lives inside one wavefront
         hint = (torch.empty((n + 31) // 32, dtype=torch.int32, device=grad_out.device),   # bitmap
                 torch.empty(1, dtype=torch.int32, device=grad_out.device))
+    skip = int(bool(skip_zero_rows) and hint is not None and out is not None)
     ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F, _DTYPES[grad_out.dtype])
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=grad_out.device)
     with torch.cuda.device(grad_out.device):
         if log_softmax:
             rc = L.gcn_log_softmax_backward_colsum(
                 _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr(), grad_pre.data_ptr(),
-                colsum.data_ptr(), n, F, hint[0].data_ptr(), hint[1].data_ptr(),
+                colsum.data_ptr(), n, F, hint[0].data_ptr(), hint[1].data_ptr(), skip,
                 ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
         else:
             rc = L.gcn_relu_dropout_backward_colsum(
                 _DTYPES[grad_out.dtype], grad_out.data_ptr(), out.data_ptr() if out is not None else None,
                 grad_pre.data_ptr() if out is not None else None, colsum.data_ptr(), n, F, float(scale),
-                hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None,
+                hint[0].data_ptr() if hint else None, hint[1].data_ptr() if hint else None, skip,
                 ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_log_softmax_backward_colsum" if log_softmax
                   else "gcn_relu_dropout_backward_colsum")
@@ -213,14 +229,17 @@ def row_bitmap(B):
     return pack_row_flags((B != 0).any(1))
 
 
-def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False):
+def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False,
+                       skip_zero_rows=False):
     """Shared by the single-GPU and sharded autograd functions: apply the fused-epilogue mask (or
     the log_softmax backward) and (optionally) produce the bias gradient, in one HIP pass when the
-    shape allows.  Returns (grad_pre, grad_bias, row-sparsity hint or None)."""
+    shape allows.  Returns (grad_pre, grad_bias, row-sparsity hint or None).  With
+    `skip_zero_rows` and a hint in the result, only the rows of grad_pre whose hint bit is set
+    are defined (backward_with_colsum)."""
     grad_bias = None
     if want_bias or log_softmax:
         fused = backward_with_colsum(grad_out.contiguous(), out if (relu or log_softmax) else None,
-                                     scale, log_softmax)
+                                     scale, log_softmax, skip_zero_rows and (relu or log_softmax))
         if fused is not None:
             return fused if want_bias else (fused[0], None, fused[2])
     if log_softmax:   # shapes outside the kernel's envelope (e.g. 7 classes): torch ops
@@ -408,6 +427,17 @@ def set_row_compaction(enabled):
     _row_compaction = bool(enabled)
 
 
+def _hint_will_be_used(B, nz_rows):
+    """Mirror of the device-side rule (use_row_flags in gcn_spmm.hip): the product skips the
+    flagged-zero rows of its dense operand B below 3/4 non-zero rows in the wide kernel (16-byte
+    lanes, more than 32 of them per row) and below 1/8 in the narrow one."""
+    n, F = B.shape
+    v = 16 // B.element_size()
+    wide = (F % v == 0 and F // v > 32 and B.stride(1) == 1 and B.data_ptr() % 16 == 0
+            and (B.stride(0) * B.element_size()) % 16 == 0)
+    return nz_rows * 4 < n * 3 if wide else nz_rows * 8 < n
+
+
 class GraphConvFunction(torch.autograd.Function):
     """The whole layer — `torch.mm(input, weight)`, `torch.spmm(adj, support)`, `+ bias`
     (reference pygcn/layers.py:33-36) and the optional fused ReLU / dropout — as ONE autograd
@@ -447,15 +477,21 @@ class GraphConvFunction(torch.autograd.Function):
         input, weight = ctx.saved_tensors[:2]
         out = ctx.saved_tensors[2] if (ctx.relu or ctx.log_softmax) else None
         need_in, need_w, need_b = ctx.needs_input_grad[:3]
-        grad_pre, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale, need_b,
-                                                       ctx.log_softmax)
-        if not (need_in or need_w):
-            return None, None, grad_bias, None, None, None, None, None
         graph_t = ctx.graph.t()
         n = graph_t.shape[0]
-        c_flags = rows = None
-        compact = (hint is not None and _row_compaction and n >= MIN_ROWS
+        # what follows reads the host-side count of non-zero gradient rows (a stream
+        # synchronisation): large graphs only, never while capturing a hipGraph
+        sync_ok = (_row_compaction and n >= MIN_ROWS and (need_in or need_w)
                    and not torch.cuda.is_current_stream_capturing())
+        # ... and when it may, the fused backward pass does not even write the all-zero rows of
+        # grad_pre: every consumer below reads the rows flagged in the bitmap only
+        grad_pre, grad_bias, hint = _grad_pre_and_bias(grad_out, out, ctx.relu, ctx.scale, need_b,
+                                                       ctx.log_softmax, skip_zero_rows=sync_ok)
+        if not (need_in or need_w):
+            return None, None, grad_bias, None, None, None, None, None
+        c_flags = rows = None
+        compact = sync_ok and hint is not None
+        unwritten = compact and (ctx.relu or ctx.log_softmax)   # grad_pre: flagged rows only
         nz_rows = int(hint[1].item()) if compact else None
         if compact and not need_in and nz_rows * 3 < grad_pre.shape[0]:
             # First layer (its input needs no gradient) under a row-sparse grad_pre:
@@ -463,16 +499,23 @@ class GraphConvFunction(torch.autograd.Function):
             # and only the rows of A · input that meet a non-zero row of grad_pre take part: a
             # forward product restricted to those rows (c_select = the bitmap of grad_pre) and a
             # GEMM over them replace the transpose product and the full-height GEMM
-            z = spmm_csr(ctx.graph, input, tag="bwd", c_select=hint[0])
+            z = spmm_csr(ctx.graph, input, tag="bwd", c_select=hint[0],
+                         out=_maybe_poisoned((n, input.shape[1]), input.dtype, input.device))
             rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
             grad_w = _weight_grad(z.index_select(0, rows), grad_pre.index_select(0, rows))
             return None, grad_w, grad_bias, None, None, None, None, None
+        if unwritten and not _hint_will_be_used(grad_pre, nz_rows):
+            # the product below would gather every row: give the unwritten ones their zeros
+            keep = unpack_row_flags(hint[0], grad_pre.shape[0])[:, None]
+            grad_pre = torch.where(keep, grad_pre, torch.zeros_like(grad_pre[:1]))
         if compact and nz_rows * 8 < grad_pre.shape[0]:
             c_flags = torch.zeros(n, dtype=torch.uint8, device=grad_pre.device)
         # with the flags requested, all-zero rows of the product are not even written: the GEMMs
         # below read the flagged rows only
         grad_sup = spmm_csr(graph_t, grad_pre.contiguous(), tag="bwd", b_hint=hint, c_flags=c_flags,
-                            skip_zero_rows=c_flags is not None)
+                            skip_zero_rows=c_flags is not None,
+                            out=_maybe_poisoned((n, grad_pre.shape[1]), grad_pre.dtype, grad_pre.device)
+                            if c_flags is not None else None)
         if c_flags is not None:
             rows = torch.nonzero(c_flags).squeeze(1)
             if rows.numel() * 3 >= n:     # too dense to pay: make the skipped rows real zeros

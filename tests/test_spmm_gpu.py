@@ -730,6 +730,7 @@ def test_layer_backward_row_compaction(oracle, dev):
 
     def grads(compaction, fused=True):
         S.set_row_compaction(compaction)
+        S._poison_unwritten = True      # rows left unwritten on purpose hold NaN: nobody may read them
         try:
             for p in list(l1.parameters()) + list(l2.parameters()):
                 p.grad = None
@@ -744,6 +745,7 @@ def test_layer_backward_row_compaction(oracle, dev):
             return [p.grad.clone() for p in list(l1.parameters()) + list(l2.parameters())]
         finally:
             S.set_row_compaction(True)
+            S._poison_unwritten = False
 
     calls = []
     orig = S._dense_grads
@@ -1007,6 +1009,7 @@ def test_first_layer_weight_gradient_through_row_selected_product(oracle, dev):
 
     def grads(compaction):
         S.set_row_compaction(compaction)
+        S._poison_unwritten = True
         try:
             layer.zero_grad()
             seen = []
@@ -1020,9 +1023,38 @@ def test_first_layer_weight_gradient_through_row_selected_product(oracle, dev):
             return [p.grad.clone() for p in layer.parameters()], any(seen)
         finally:
             S.set_row_compaction(True)
+            S._poison_unwritten = False
 
     sel, used = grads(True)
     ref, used_ref = grads(False)
     assert used and not used_ref
     for a_, b_ in zip(sel, ref):
         assert_normwise(a_.cpu(), b_.cpu().numpy(), TOL, "row-selected grad_W")
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (128, torch.bfloat16)])
+def test_backward_passes_skip_zero_rows(dev, F, dtype):
+    """skip_zero_rows of the fused backward passes: the rows flagged in the bitmap equal the
+    full result, every other row is left untouched (NaN pre-fill survives), column sums, bitmap
+    and count are unchanged."""
+    import importlib
+    S = importlib.import_module("pygcn_amd.spmm")
+    n = 6000
+    gen = torch.Generator(device=dev).manual_seed(F + 5)
+    g = (torch.randn(n, F, generator=gen, device=dev)
+         * (torch.rand(n, 1, generator=gen, device=dev) < 0.07)).to(dtype)
+    out_relu = torch.relu(torch.randn(n, F, generator=gen, device=dev)).to(dtype)
+    logp = torch.log_softmax(torch.randn(n, F, generator=gen, device=dev), 1).to(dtype)
+    for out, kw in ((out_relu, dict(scale=2.0)), (logp, dict(log_softmax=True))):
+        full, cs, hint = S.backward_with_colsum(g, out, **kw)
+        S._poison_unwritten = True
+        try:
+            part, cs2, hint2 = S.backward_with_colsum(g, out, skip_zero_rows=True, **kw)
+        finally:
+            S._poison_unwritten = False
+        keep = S.unpack_row_flags(hint[0], n)
+        assert torch.equal(hint2[0], hint[0]) and int(hint2[1]) == int(hint[1]) == int(keep.sum())
+        assert torch.equal(cs2, cs)
+        assert torch.equal(part[keep], full[keep])
+        assert bool(part[~keep].isnan().all()) and 0 < int(keep.sum()) < n
+        assert bool((full[~keep] == 0).all())
