@@ -1058,3 +1058,39 @@ def test_backward_passes_skip_zero_rows(dev, F, dtype):
         assert torch.equal(part[keep], full[keep])
         assert bool(part[~keep].isnan().all()) and 0 < int(keep.sum()) < n
         assert bool((full[~keep] == 0).all())
+
+
+@pytest.mark.parametrize("fout,share", [(256, 0.5), (256, 0.9), (64, 0.05), (64, 0.3), (64, 0.9)])
+def test_unwritten_rows_are_never_read(dev, fout, share):
+    """The backward pass leaves all-zero gradient rows unwritten only as long as the product that
+    follows skips them (device-side rule: < 3/4 non-zero rows in the wide kernel, < 1/8 in the
+    narrow one — mirrored on the host by _hint_will_be_used); above the threshold they must get
+    real zeros first.  With the NaN pre-fill every mistake shows as a NaN gradient."""
+    import importlib
+    from pygcn_amd import CSRGraph, GraphConvolution
+    from pygcn_amd.utils import rmat_graph
+    S = importlib.import_module("pygcn_amd.spmm")
+    n = 1 << 17
+    rowptr, col, val = rmat_graph(n, 3 * n, seed=11, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    torch.manual_seed(0)
+    layer = GraphConvolution(32, fout).to(dev)
+    x = torch.randn(n, 32, device=dev, requires_grad=True)      # general path (grad_input needed)
+    rows = torch.nonzero(torch.rand(n, device=dev) < share).squeeze(1)
+    w = torch.randn(rows.numel(), fout, device=dev)
+
+    def run(poison, compaction):
+        S._poison_unwritten, _ = poison, S.set_row_compaction(compaction)
+        try:
+            layer.zero_grad()
+            x.grad = None
+            (layer(x, g, relu=True)[rows] * w).sum().backward()
+            return [x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        finally:
+            S._poison_unwritten = False
+            S.set_row_compaction(True)
+
+    got, ref = run(True, True), run(False, False)
+    for a_, b_ in zip(got, ref):
+        assert bool(a_.isfinite().all())
+        assert_normwise(a_.cpu(), b_.cpu().numpy(), TOL, "skip-write path vs plain path")
