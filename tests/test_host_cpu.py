@@ -197,3 +197,24 @@ def test_rmat_generator_shapes():
     key = rows * n + col
     assert bool((key[1:] > key[:-1]).all())         # sorted, no duplicates
     assert int(deg.max()) > 20 * float(deg.float().median())   # skewed
+
+
+def test_ctypes_structs_follow_the_header_field_by_field():
+    """The ctypes mirrors must list the fields of `struct gcn_csr_plan` / `struct gcn_epilogue`
+    in the header's order with matching widths (a silent mismatch would shift every later
+    field)."""
+    hdr = open(os.path.join(ROOT, "include", "gcn_spmm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    width = {"int32_t": 4, "int64_t": 8, "uint64_t": 8, "float": 4}
+    for cname, mirror in (("gcn_csr_plan", _native.GcnCsrPlan), ("gcn_epilogue", _native.GcnEpilogue)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.match(r"(?:const )?([A-Za-z0-9_]+) (\*?)([A-Za-z0-9_]+)$", decl)
+            assert m, decl
+            fields.append((m.group(3), 8 if m.group(2) else width[m.group(1)]))
+        got = [(n, ctypes.sizeof(t)) for n, t in mirror._fields_]
+        assert got == fields, (cname, got, fields)
