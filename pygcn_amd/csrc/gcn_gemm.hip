@@ -29,7 +29,8 @@
 // Steps that paid: s_setprio around the MFMA run (4 %), split behind the MFMA run + B-fragment
 // double buffering (4 %), two steps per barrier (2 %).  Tried without gain: X staged through
 // wave-private LDS in full 128-B lines, 4-wave workgroups, a deeper X ring, persistent workgroups
-// with cross-tile prefetch (spills at 256 VGPRs).  Next would be the guide's multi-phase schedule
+// with cross-tile prefetch (spills at 256 VGPRs), storing each column block under the MFMAs of
+// the next one in the last K step (7.63 vs 7.62 ms).  Next would be the guide's multi-phase schedule
 // (LDS-DMA for the W stream, staggered wave halves).
 #include <hip/hip_runtime.h>
 
