@@ -203,7 +203,8 @@ int gcn_relu_dropout_backward(int dtype, const void *grad_out, const void *out, 
  * sums of grad_out; grad_pre is then ignored).  Deterministic (per-block partial rows added in
  * block order, no float atomics).  F must be a multiple of the 16-byte lane width v (4 fp32 / 8
  * bf16) with F/v dividing 256; scratch: gcn_bwd_colsum_workspace_bytes(n_rows, F, dtype).
- * Optional outputs (both or neither; F/v <= 64): bit r of row_bits[ceil(n_rows/32)] is set where
+ * Optional outputs (both or neither; F/v <= 64, GCN_E_BADARG for wider rows — they are never
+ * silently left unwritten): bit r of row_bits[ceil(n_rows/32)] is set where
  * row r of the result has a non-zero element, *nnz_rows = how many — the B-operand hint of
  * gcn_epilogue.  skip_zero_rows != 0 (needs those outputs and `out`): rows of the result that are
  * entirely zero are NOT written to grad_pre — for a consumer that reads the flagged rows only

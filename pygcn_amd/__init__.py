@@ -7,8 +7,11 @@ cwd = this directory: `from layers import GraphConvolution`, `from models import
 `from utils import load_data, accuracy`.  Package use: `from pygcn_amd import GCN, ...`.
 """
 from .graph import CSRGraph, as_graph
-from .spmm import spmm, spmm_csr
+from .spmm import spmm_csr
+from .ops import sparse_mm          # also registers torch.ops.pygcn_amd.spmm_csr
 from .layers import GraphConvolution
 from .models import GCN
 
-__all__ = ["CSRGraph", "as_graph", "spmm", "spmm_csr", "GraphConvolution", "GCN"]
+# `pygcn_amd.spmm` is the MODULE (kernels' Python launchers + autograd nodes); the drop-in for
+# `torch.spmm` / `torch.sparse.mm` is exported as `sparse_mm`.
+__all__ = ["CSRGraph", "as_graph", "sparse_mm", "spmm_csr", "GraphConvolution", "GCN"]

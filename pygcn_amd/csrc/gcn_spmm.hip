@@ -1398,7 +1398,8 @@ static int bwd_colsum_impl(const char *who, int mode, int dtype, const void *gra
         return bad(GCN_E_BADARG, "F must be a multiple of the 16-byte lane width with F/width dividing 256");
     if (mode == 2 && F / vec > 64)
         return bad(GCN_E_BADARG, "a row must fit one wavefront (F / lane width <= 64)");
-    if (row_bits != nullptr && F / vec > 64) { row_bits = nullptr; nnz_rows = nullptr; }   // row > 1 wave
+    if (row_bits != nullptr && F / vec > 64)   // a row spans several wavefronts: no per-row ballot
+        return bad(GCN_E_BADARG, "row_bits / nnz_rows need F / lane width <= 64 (pass NULL for wider rows)");
     if (skip_zero_rows && (row_bits == nullptr || mode == 0))
         return bad(GCN_E_BADARG, "skip_zero_rows needs the row bitmap outputs and a result tensor");
     if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))

@@ -13,12 +13,43 @@ Replaces the torch sparse COO tensor the reference builds once at load time
 
 Conversions from torch / scipy layouts are one-off host+device plumbing done with torch ops.
 """
+import collections
 import ctypes
+import weakref
 
 import numpy as np
 import torch
 
 from . import _native
+
+# CSR arrays -> the prepared handle built on them: the registered operator
+# (`torch.ops.pygcn_amd.spmm_csr`, pygcn_amd/ops.py) receives plain tensors and finds the cached
+# schedule / transpose here.  Keys are the arrays' device addresses, which stay unique for as long
+# as the handle (which owns the arrays) lives; handles built for arrays nobody else holds a
+# CSRGraph for are kept alive by a small LRU.
+_BY_ARRAYS = weakref.WeakValueDictionary()
+_RECENT = collections.OrderedDict()
+_RECENT_MAX = 8
+
+
+def _arrays_key(rowptr, col, val, shape):
+    return (rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), rowptr.dtype, int(shape[0]),
+            int(shape[1]), int(col.numel()))
+
+
+def graph_for_arrays(rowptr, col, val, shape):
+    """The CSRGraph built on exactly these device arrays (same storage), constructing and caching
+    one if there is none: schedule and transpose are then built once per adjacency, not per call."""
+    key = _arrays_key(rowptr, col, val, shape)
+    g = _BY_ARRAYS.get(key)
+    if g is None:
+        g = CSRGraph(rowptr, col, val, shape)
+        key = _arrays_key(g.rowptr, g.col, g.val, g.shape)   # (.contiguous() may have copied)
+    _RECENT[key] = g
+    _RECENT.move_to_end(key)
+    while len(_RECENT) > _RECENT_MAX:
+        _RECENT.popitem(last=False)
+    return g
 
 
 def _require_cuda(t, what):
@@ -63,6 +94,8 @@ class CSRGraph:
         self._plan = None
         self._keep = None
         self._t = None
+        self._t_val_version = None
+        _BY_ARRAYS[_arrays_key(self.rowptr, self.col, self.val, self.shape)] = self
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -175,6 +208,8 @@ class CSRGraph:
         """CSR(A^T), built once on the device by the native ingest kernel
         (`gcn_csr_transpose_device`: stable radix sort by column).  Within each row of A^T the
         entries are in increasing source-row order, so backward sums are deterministic."""
+        if self._t is not None and self._t_val_version != self.val._version:
+            self._t = None        # the values were edited in place since the transpose was built
         if self._t is None:
             n_rows, n_cols = self.shape
             dev = self.device
@@ -194,8 +229,8 @@ class CSRGraph:
             del ws
             g = CSRGraph(rowptr_t, col_t, val_t, (n_cols, n_rows), item_cost=self.item_cost,
                          long_thresh=self.long_thresh, validate=False)
-            g._t = self
-            self._t = g
+            g._t, g._t_val_version = self, val_t._version
+            self._t, self._t_val_version = g, self.val._version
         return self._t
 
     def row_normalize_(self):

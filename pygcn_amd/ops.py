@@ -1,0 +1,79 @@
+"""`torch.ops.pygcn_amd.spmm_csr` — the sparse x dense product of the GraphConvolution layer as a
+REGISTERED PyTorch operator ("operator / FFI" row).
+
+Replaces the call `torch.spmm(adj, support)` at reference pygcn/layers.py:34 and, through the
+registered autograd formula, the product `adj.t() @ grad_output` PyTorch's `mm` derivative runs for
+it when `loss.backward()` is called (pygcn/train.py:157):
+
+    C       = spmm_csr(rowptr, col, val, B, bias, n_cols, relu)          A · B (+ bias, ReLU)
+    grad_B  = spmm_csr(rowptr_T, col_T, val_T, grad_C, None, n_rows)     Aᵀ · grad_C
+    grad_b  = column sums of grad_C
+
+The operator takes plain tensors (CSR arrays of Â on the HIP device), so it is visible to the
+dispatcher, `torch.library.opcheck`, and `torch.compile` (a fake/meta kernel is registered).  The
+HIP kernel behind it is the C-ABI launcher `gcn_spmm_csr_ep` (include/gcn_spmm.h); the schedule
+and CSR(Âᵀ) for a given set of arrays are built once and cached (pygcn_amd/graph.py,
+`graph_for_arrays`).  There is NO CPU kernel: calling the operator with CPU tensors raises.
+"""
+from typing import Optional
+
+import torch
+
+from . import spmm as _spmm
+from .graph import CSRGraph, graph_for_arrays
+
+_NO_CPU = ("pygcn_amd::spmm_csr must run on a HIP device: the MI355X path has no CPU "
+           "implementation; move the tensors with .cuda().")
+
+
+@torch.library.custom_op("pygcn_amd::spmm_csr", mutates_args=(), device_types="cuda")
+def spmm_csr_op(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, B: torch.Tensor,
+                bias: Optional[torch.Tensor], n_cols: int, relu: bool = False) -> torch.Tensor:
+    graph = graph_for_arrays(rowptr, col, val, (rowptr.numel() - 1, n_cols))
+    return _spmm.spmm_csr(graph, B, bias=bias, relu=relu)
+
+
+@spmm_csr_op.register_kernel("cpu")
+def _(rowptr, col, val, B, bias, n_cols, relu=False):
+    raise RuntimeError(_NO_CPU)
+
+
+@spmm_csr_op.register_fake
+def _(rowptr, col, val, B, bias, n_cols, relu=False):
+    torch._check(B.dim() == 2, lambda: "dense operand must be 2-D")
+    torch._check(B.shape[0] == n_cols,
+                 lambda: f"size mismatch, adj [*, {n_cols}] x dense {tuple(B.shape)}")
+    return B.new_empty((rowptr.shape[0] - 1, B.shape[1]))
+
+
+def _setup_context(ctx, inputs, output):
+    rowptr, col, val, B, bias, n_cols, relu = inputs
+    ctx.n_cols, ctx.relu = n_cols, bool(relu)
+    ctx.bias_dtype = bias.dtype if bias is not None else None
+    ctx.save_for_backward(rowptr, col, val, *([output] if relu else []))
+
+
+def _backward(ctx, grad_out):
+    rowptr, col, val = ctx.saved_tensors[:3]
+    grad_B = grad_bias = None
+    if ctx.relu:
+        grad_out = _spmm.relu_dropout_backward(grad_out.contiguous(), ctx.saved_tensors[3])
+    if ctx.needs_input_grad[3]:
+        gt = graph_for_arrays(rowptr, col, val, (rowptr.numel() - 1, ctx.n_cols)).t()
+        grad_B = torch.ops.pygcn_amd.spmm_csr(gt.rowptr, gt.col, gt.val, grad_out.contiguous(),
+                                              None, gt.shape[1], False)
+    if ctx.bias_dtype is not None and ctx.needs_input_grad[4]:
+        grad_bias = grad_out.sum(0).to(ctx.bias_dtype)
+    return None, None, None, grad_B, grad_bias, None, None
+
+
+spmm_csr_op.register_autograd(_backward, setup_context=_setup_context)
+
+
+def sparse_mm(adj, dense, bias=None):
+    """Drop-in for `torch.spmm(adj, dense)` / `torch.sparse.mm` (+ optional fused bias) with
+    autograd, through the registered operator.  `adj`: CSRGraph or a torch sparse COO/CSR tensor
+    on the HIP device (converted once, cached on the tensor)."""
+    from .graph import as_graph
+    g = adj if isinstance(adj, CSRGraph) else as_graph(adj)
+    return torch.ops.pygcn_amd.spmm_csr(g.rowptr, g.col, g.val, dense, bias, g.shape[1], False)

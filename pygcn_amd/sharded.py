@@ -96,14 +96,80 @@ def transpose_row_block(rowptr, col, val, n_rows, r0, r1):
     return rp.to(rowptr.dtype), s[perm], v[perm]
 
 
-def _p2p_round(sends, recvs, group):
-    """One grouped round of point-to-point transfers: sends = [(tensor, peer)], recvs likewise.
-    Zero-length transfers are skipped on both sides (counts are known everywhere)."""
+def _p2p_begin(sends, recvs, group):
+    """Post one grouped round of point-to-point transfers: sends = [(tensor, peer)], recvs
+    likewise; returns the pending work handles.  Zero-length transfers are skipped on both sides
+    (counts are known everywhere).  On RCCL the transfers run on the communicator's own stream,
+    ordered after what the current stream has enqueued so far: kernels launched on the current
+    stream between begin and end overlap them."""
     ops = [dist.P2POp(dist.isend, t, peer, group) for t, peer in sends if t.numel()] + \
           [dist.P2POp(dist.irecv, t, peer, group) for t, peer in recvs if t.numel()]
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
+def _p2p_end(pending):
+    """Make the current stream (the host, with gloo) wait for the posted transfers."""
+    for w in pending:
+        w.wait()
+
+
+def _p2p_round(sends, recvs, group):
+    """One grouped round of point-to-point transfers, complete on return."""
+    _p2p_end(_p2p_begin(sends, recvs, group))
+
+
+def _owner_of(ids, bounds_t, world):
+    """Rank that owns each global row id (bounds may repeat: empty blocks own nothing)."""
+    return (torch.searchsorted(bounds_t, ids, right=True) - 1).clamp_(0, world - 1)
+
+
+def transpose_block_by_exchange(a_block, bounds, rank, world, group=None):
+    """Rows [b_r, b_r+1) of Aᵀ from the row blocks of A held by the ranks, WITHOUT any rank ever
+    holding the whole matrix: every rank buckets the stored entries of its block by the owner of
+    their column and sends (column, global row, value) triplets straight to that owner (one
+    grouped point-to-point round); the owner sorts what it received by (column, row).  Within each
+    row of Aᵀ the entries come out in increasing source-row order — the order of
+    `transpose_row_block` and of the single-GPU `gcn_csr_transpose_device`, so backward sums are
+    deterministic and independent of the number of ranks.  Collective; O(nnz / P) memory."""
+    rowptr, col, val = a_block
+    dev = col.device
+    n_global, r0, r1 = int(bounds[-1]), bounds[rank], bounds[rank + 1]
+    b = torch.tensor(bounds, dtype=torch.int64, device=dev)
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    grow = torch.repeat_interleave(torch.arange(r0, r1, device=dev, dtype=torch.int64), deg)
+    key = col.to(torch.int64) * n_global + grow              # sorts by (column, source row)
+    key, perm = torch.sort(key)
+    v = val[perm]
+    del perm, grow
+    cut = torch.searchsorted(key, b * n_global)               # segment of each owner
+    mine = (cut[1:] - cut[:-1]).contiguous()                  # entries I hold for each owner
+    M = torch.empty(world * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(M, mine, group=group)
+    M = M.view(world, world).tolist()                         # M[s][r]: s holds for r
+    cut = cut.tolist()
+    rk = {s: torch.empty(M[s][rank], dtype=torch.int64, device=dev) for s in range(world) if s != rank}
+    rv = {s: torch.empty(M[s][rank], dtype=torch.float32, device=dev) for s in range(world) if s != rank}
+    sends, recvs = [], []
+    for k in range(1, world):
+        p = (rank + k) % world
+        sends += [(key[cut[p]:cut[p + 1]], p), (v[cut[p]:cut[p + 1]], p)]
+    for k in range(1, world):
+        q = (rank - k) % world
+        recvs += [(rk[q], q), (rv[q], q)]
+    _p2p_round(sends, recvs, group)
+    keys = torch.cat([key[cut[rank]:cut[rank + 1]] if s == rank else rk[s] for s in range(world)])
+    vals = torch.cat([v[cut[rank]:cut[rank + 1]] if s == rank else rv[s] for s in range(world)])
+    del key, v, rk, rv
+    keys, perm = torch.sort(keys)
+    vals = vals[perm]
+    del perm
+    c = keys // n_global                                       # my rows of Aᵀ (global ids)
+    src = (keys - c * n_global).to(torch.int32)
+    counts = torch.bincount(c - r0, minlength=r1 - r0) if c.numel() else torch.zeros(
+        r1 - r0, dtype=torch.int64, device=dev)
+    rp = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rp[1:])
+    return rp.to(rowptr.dtype), src, vals
 
 
 class HaloExchange:
@@ -138,6 +204,7 @@ class HaloExchange:
             assert int(self.send_idx.max()) < self.n_local and int(self.send_idx.min()) >= 0
         self.n_halo = sum(recv_counts)
         self.n_send = sum(self.send_counts)
+        self.last_recv_bytes = 0
         # start of each peer's segment in send_idx / in the packed send buffer (peers in rank order)
         self.send_off, acc = [], 0
         for s in range(world):
@@ -154,20 +221,23 @@ class HaloExchange:
         idx = torch.searchsorted(needed, c)
         base = torch.tensor([self.n_local + halo_off[r] - pos_l[r] for r in range(world)],
                             dtype=torch.int64, device=dev)
-        self.col_local = torch.where(owner == rank, c - bounds[rank], base[owner] + idx) \
+        self.is_own = owner == rank          # per stored entry: references one of my own rows
+        self.col_local = torch.where(self.is_own, c - bounds[rank], base[owner] + idx) \
             .to(torch.int32)
         self.n_buf = self.n_local + self.n_halo
 
-    def exchange(self, local):
-        """[n_local, F] -> the referenced remote rows [n_halo, F].  The rank's own rows are NOT
-        copied: the product reads them in place from `local` and the halo rows from the returned
-        buffer (two-block dense operand, gcn_epilogue.b2)."""
+    def exchange_begin(self, local):
+        """Pack the rows the peers asked for and POST the grouped transfers; returns (halo buffer
+        [n_halo, F], pending handles).  The buffer is defined only after exchange_end(pending);
+        work enqueued in between (the product over the rank's own rows) overlaps the transfers.
+        The rank's own rows are NOT copied: the product reads them in place from `local` and the
+        halo rows from the returned buffer (two-block dense operand, gcn_epilogue.b2)."""
         F = local.shape[1]
         halo = torch.empty((self.n_halo, F), dtype=local.dtype, device=local.device)
         if self.world == 1:
-            return halo
+            return halo, []
         packed = local.index_select(0, self.send_idx)
-        sends, recvs, so = [], [], 0
+        sends, recvs = [], []
         for k in range(1, self.world):
             s = (self.rank + k) % self.world
             off = sum(self.send_counts[q] for q in range(s) if q != self.rank)
@@ -176,7 +246,19 @@ class HaloExchange:
             r = (self.rank - k) % self.world
             o = self.halo_off[r]
             recvs.append((halo[o:o + self.recv_counts[r]], r))
-        _p2p_round(sends, recvs, self.group)
+        pending = _p2p_begin(sends, recvs, self.group)
+        self.last_recv_bytes = self.n_halo * F * local.element_size()
+        return halo, (pending, packed)       # (the packed rows must outlive the sends)
+
+    @staticmethod
+    def exchange_end(pending):
+        if pending:
+            _p2p_end(pending[0])
+
+    def exchange(self, local):
+        """[n_local, F] -> the referenced remote rows [n_halo, F], complete on return."""
+        halo, pending = self.exchange_begin(local)
+        self.exchange_end(pending)
         return halo
 
     def exchange_sparse(self, local, row_nonzero):
@@ -189,6 +271,7 @@ class HaloExchange:
         F, dev, W = local.shape[1], local.device, self.world
         halo = torch.zeros((self.n_halo, F), dtype=local.dtype, device=dev)
         self.last_halo_nonzero = torch.zeros(self.n_halo, dtype=torch.bool, device=dev)
+        self.last_recv_bytes = 0
         if W == 1:
             return halo
         keep = row_nonzero(self.send_idx)                                   # [n_send] bool
@@ -221,6 +304,7 @@ class HaloExchange:
                 halo.index_copy_(0, dst, rr)
                 self.last_halo_nonzero[dst] = True
         self.last_sparse_rows = (int(nz.numel()), self.n_send)              # sent / dense (stats)
+        self.last_recv_bytes = sum(int(rp.numel()) for _, rp, _ in landed) * (F * local.element_size() + 4)
         return halo
 
 
@@ -230,9 +314,13 @@ class ShardedGraph:
 
     def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
                  graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias,
-                 sparse_grad_exchange=True, **plan_kw):
+                 sparse_grad_exchange=True, overlap=True, **plan_kw):
         if exchange not in ("halo", "allgather"):
             raise RuntimeError("exchange must be 'halo' or 'allgather'")
+        # dense halo exchanges are pipelined by source block (own rows | halo rows), see product()
+        self.overlap = bool(overlap) and exchange == "halo" and world > 1
+        self._graph_factory, self._plan_kw = graph_factory, plan_kw
+        self._split = {}       # transpose? -> (A_own, A_halo_plus_identity), built on first use
         # backward exchanges send only the non-zero gradient rows (halo mode; must be set
         # identically on every rank: it selects the message protocol)
         self.sparse_grad_exchange = bool(sparse_grad_exchange) and exchange == "halo"
@@ -258,6 +346,8 @@ class ShardedGraph:
                 blocks.append((graph_factory(rp, remap_columns(c, bounds, self.max_rows), v,
                                              (self.n_local, n_pad), **plan_kw), None))
         (self.A, self.halo), (self.At, self.halo_t) = blocks
+        self._raw = {False: (a_block[0], a_block[2]), True: (at_block[0], at_block[2])}
+        self.last_recv_bytes = {"fwd": 0, "bwd": 0}   # bytes this rank received in the last exchange
         self.timing = None    # optional list: (tag, start_event, end_event) per exchange+product
         self._const_ref = None      # weakref to the registered constant input (feature matrix)
         self._const_halo = None     # (version, halo rows) of that tensor
@@ -265,7 +355,9 @@ class ShardedGraph:
 
     @classmethod
     def from_global_csr(cls, rowptr, col, val, n, rank, world, device=None, group=None, **kw):
-        """Every rank holds (or has generated) the same global CSR; keep this rank's blocks."""
+        """Every rank holds (or has generated) the same global CSR; keep this rank's blocks.
+        For graphs that fit one process (tests, small inputs); see from_row_block / from_rmat for
+        construction that never materialises the whole matrix on a rank."""
         bounds = partition_rows(rowptr, world)
         r0, r1 = bounds[rank], bounds[rank + 1]
         a_block = row_block(rowptr, col, val, r0, r1)
@@ -275,18 +367,81 @@ class ShardedGraph:
             at_block = tuple(t.to(device) for t in at_block)
         return cls(bounds, rank, world, a_block, at_block, group=group, **kw)
 
+    @classmethod
+    def from_row_block(cls, bounds, rank, world, a_block, group=None, **kw):
+        """Shard-local construction: this rank supplies ONLY its rows [b_r, b_r+1) of Â (rebased
+        rowptr, global column ids, values); its rows of Âᵀ are assembled from the triplets the
+        other ranks hold for it (transpose_block_by_exchange).  Collective.  Per-rank memory is
+        O(nnz / P): a graph larger than one GPU can be ingested."""
+        at_block = transpose_block_by_exchange(a_block, bounds, rank, world, group)
+        return cls(bounds, rank, world, a_block, at_block, group=group, **kw)
+
+    @classmethod
+    def from_rmat(cls, n, n_edges, rank, world, device, seed=42, perm_seed=43, group=None, **kw):
+        """The synthetic graph of configs C3–C5 (`utils.rmat_graph(n, n_edges, seed, perm_seed)`:
+        the same matrix, entry for entry) built shard-locally: (1) every rank generates the rows of
+        a provisional uniform block and counts their stored entries, (2) the counts are
+        all-gathered (n integers) and give the nnz-balanced bounds, (3) every rank generates its
+        final row block, (4) the Âᵀ blocks are assembled by the triplet exchange.  The edge stream
+        is replayed, never stored: O(chunk) + O(nnz / P) memory per rank."""
+        from .utils import rmat_row_block
+        step = -(-n // world)
+        p0, p1 = min(rank * step, n), min((rank + 1) * step, n)
+        deg = torch.zeros(step, dtype=torch.int64, device=device)
+        deg[:p1 - p0] = rmat_row_block(n, n_edges, p0, p1, seed, perm_seed, device, counts_only=True)
+        allc = torch.empty(world * step, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allc, deg, group=group)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(allc[:n], 0, out=rowptr[1:])      # blocks are contiguous: padding only at the end
+        bounds = partition_rows(rowptr, world)
+        del rowptr, allc, deg
+        a_block = rmat_row_block(n, n_edges, bounds[rank], bounds[rank + 1], seed, perm_seed, device)
+        return cls.from_row_block(bounds, rank, world, a_block, group=group, **kw)
+
     # ---------------------------------------------------------------- exchange step
     def all_gather_rows(self, local):
         """[n_local, F] on every rank -> padded [P*max_rows, F] (rows past n_local of each slot
         are never referenced by the remapped column indices)."""
         F = local.shape[1]
         out = torch.empty((self.world * self.max_rows, F), dtype=local.dtype, device=local.device)
-        slot = out[self.rank * self.max_rows:(self.rank + 1) * self.max_rows]
-        slot[:self.n_local].copy_(local)
-        if self.n_local < self.max_rows:
-            slot[self.n_local:].zero_()
-        dist.all_gather_into_tensor(out, slot, group=self.group)   # in-place form
+        if self.n_local == self.max_rows and local.is_contiguous():
+            slot = local
+        else:
+            slot = torch.zeros((self.max_rows, F), dtype=local.dtype, device=local.device)
+            slot[:self.n_local].copy_(local)
+        dist.all_gather_into_tensor(out, slot, group=self.group)
         return out
+
+    def split_block(self, transpose=False):
+        """The rank's block cut by SOURCE block for the pipelined dense exchange:
+            A_own  [n_local, n_local]            entries that reference the rank's own rows
+            A_halo [n_local, n_halo + n_local]   entries that reference halo rows, plus one entry
+                                                 (i, n_halo + i) = 1 per row
+        so that   out = A_halo · [halo rows ; A_own · own rows]   equals the block's product: the
+        identity entries add the partial result of the own-rows product (second block of the
+        two-block dense operand) inside the same launch that applies the fused epilogue — no
+        accumulate mode, no extra pass.  Built once per block on first use."""
+        if transpose not in self._split:
+            h = self.halo_t if transpose else self.halo
+            rowptr, val = self._raw[transpose]
+            dev, n_loc = val.device, self.n_local
+            deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+            row = torch.repeat_interleave(torch.arange(n_loc, device=dev, dtype=torch.int64), deg)
+            own = h.is_own
+
+            def csr(rows, cols, vals, n_cols):
+                rp = torch.zeros(n_loc + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(torch.bincount(rows, minlength=n_loc), 0, out=rp[1:])
+                return self._graph_factory(rp.to(rowptr.dtype), cols.to(torch.int32), vals,
+                                           (n_loc, n_cols), **self._plan_kw)
+            a_own = csr(row[own], h.col_local[own], val[own], n_loc)
+            ident = torch.arange(n_loc, device=dev, dtype=torch.int64)
+            rows = torch.cat([row[~own], ident])
+            cols = torch.cat([h.col_local[~own].to(torch.int64) - n_loc, ident + h.n_halo])
+            vals = torch.cat([val[~own], torch.ones(n_loc, dtype=val.dtype, device=dev)])
+            rows, perm = torch.sort(rows, stable=True)       # halo entries first, identity last
+            self._split[transpose] = (a_own, csr(rows, cols[perm], vals[perm], h.n_halo + n_loc))
+        return self._split[transpose]
 
     # ---------------------------------------------------------------- constant input
     def register_constant_input(self, t):
@@ -323,23 +478,43 @@ class ShardedGraph:
         """Exchange + local product.  `row_nonzero` (callable idx -> bool, see
         HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel;
         with `own_flags` (bool [n_local], the same information for all own rows) the local product
-        also gets the operand hint [own flags | flags of the received rows] and skips zero rows."""
+        also gets the operand hint [own flags | flags of the received rows] and skips zero rows.
+
+        A dense halo exchange is PIPELINED BY SOURCE BLOCK (SURVEY §8e lever i): the transfers are
+        posted, the product over the entries that reference the rank's own rows runs while the
+        halo rows are in flight, and the product over the halo entries (which folds the first
+        partial result in through its identity entries and applies the epilogue) follows the
+        arrival — see split_block()."""
         ev = self._tic(local)
         kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
+        tag = "bwd_local" if transpose else "fwd_local"
+        which = "bwd" if transpose else "fwd"
         if self.exchange_mode == "halo":
             h = self.halo_t if transpose else self.halo
+            if row_nonzero is None and self.overlap:
+                a_own, a_halo = self.split_block(transpose)
+                halo, pending = h.exchange_begin(local)
+                part = self._spmm(a_own, local, tag=tag)          # overlaps the transfers
+                h.exchange_end(pending)
+                out = self._spmm(a_halo, halo, bias=bias, relu=relu, tag=tag, B2=part, **kw)
+                self.last_recv_bytes[which] = h.last_recv_bytes
+                self._toc(ev, which)
+                return out
             halo = h.exchange_sparse(local, row_nonzero) if row_nonzero is not None else \
                 h.exchange(local)
+            self.last_recv_bytes[which] = h.last_recv_bytes
             if row_nonzero is not None and own_flags is not None and self._hinted_product:
                 kw["b_hint"] = pack_row_flags(torch.cat([own_flags, h.last_halo_nonzero]))
             # dense operand = [own rows (in place) ; halo rows]
             out = self._spmm(self.At if transpose else self.A, local, bias=bias, relu=relu,
-                             tag="bwd_local" if transpose else "fwd_local", B2=halo, **kw)
+                             tag=tag, B2=halo, **kw)
         else:
             gathered = self.all_gather_rows(local)
+            self.last_recv_bytes[which] = ((self.world - 1) * self.max_rows * local.shape[1]
+                                           * local.element_size())
             out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
-                             tag="bwd_local" if transpose else "fwd_local", **kw)
-        self._toc(ev, "bwd" if transpose else "fwd")
+                             tag=tag, **kw)
+        self._toc(ev, which)
         return out
 
     def exchange_rows(self):

@@ -252,24 +252,39 @@ def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False,
     return grad_out, grad_bias, None
 
 
-def next_dropout_seed():
-    """64-bit seed drawn from torch's default CPU generator: reproducible under
-    torch.manual_seed, no device synchronisation."""
-    return int(torch.empty((), dtype=torch.int64).random_().item())
+def next_dropout_seed(device=None):
+    """64-bit seed of one fused-dropout launch, drawn the way `F.dropout` draws on a GPU in the
+    reference model (pygcn/models.py:50 upstream): from the DEVICE's default generator — its seed
+    (set by torch.manual_seed / torch.cuda.manual_seed) and its Philox offset, which is advanced —
+    so it is reproducible under torch.manual_seed, needs no device synchronisation and leaves
+    torch's CPU generator alone (a caller sharing that generator sees the stream the reference
+    would give it).  CPU tensors (test stand-ins of the sharded path only) draw from the CPU
+    generator, as F.dropout on CPU does."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+            else torch.device("cpu")
+    if device.type != "cuda":
+        return int(torch.empty((), dtype=torch.int64).random_().item())
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[index]
+    offset = gen.get_offset()
+    gen.set_offset(offset + 4)          # one Philox counter step, like one dropout launch
+    mixed = (gen.initial_seed() * 0x9E3779B97F4A7C15 + (offset // 4 + 1) * 0xD1B54A32D192ED03)
+    return mixed & 0xFFFFFFFFFFFFFFFF
 
 
 _device_seeds = {}
 
 
 def dropout_seed_for(tensor):
-    """Seed of one fused-dropout launch on `tensor`'s device.  Normally a host integer drawn from
-    torch's CPU generator (next_dropout_seed).  While the stream is being captured into a
+    """Seed of one fused-dropout launch on `tensor`'s device.  Normally a host integer derived
+    from the device generator's (seed, offset) (next_dropout_seed).  While the stream is being captured into a
     hipGraph a host seed would be frozen into the captured kernel arguments — the same mask on
     every replay — so the launch then reads a per-device int64 tensor that an op recorded in the
     same capture advances: every replay masks differently.  The tensor is created by the first
     eager dropout launch on the device (the warm-up steps torch requires before a capture)."""
     if not tensor.is_cuda:
-        return next_dropout_seed()
+        return next_dropout_seed(tensor.device)
     capturing = torch.cuda.is_current_stream_capturing()
     key = tensor.device.index if tensor.device.index is not None else torch.cuda.current_device()
     t = _device_seeds.get(key)
@@ -282,7 +297,7 @@ def dropout_seed_for(tensor):
         t = _device_seeds[key] = torch.full((1,), torch.initial_seed() & (2 ** 63 - 1),
                                             dtype=torch.int64, device=tensor.device)
     if not capturing:
-        return next_dropout_seed()
+        return next_dropout_seed(tensor.device)
     t.add_(0x9E3779B97F4A7C15 - (1 << 64))   # odd increment, wraps; recorded in the capture
     return t
 
@@ -493,14 +508,19 @@ class GraphConvFunction(torch.autograd.Function):
         compact = sync_ok and hint is not None
         unwritten = compact and (ctx.relu or ctx.log_softmax)   # grad_pre: flagged rows only
         nz_rows = int(hint[1].item()) if compact else None
-        if compact and not need_in and nz_rows * 3 < grad_pre.shape[0]:
+        if (compact and not need_in and nz_rows * 3 < grad_pre.shape[0]
+                and input.shape[1] <= 2 * grad_pre.shape[1]):
             # First layer (its input needs no gradient) under a row-sparse grad_pre:
             #     grad_W = inputᵀ · (Aᵀ · grad_pre) = (A · input)ᵀ · grad_pre,
             # and only the rows of A · input that meet a non-zero row of grad_pre take part: a
             # forward product restricted to those rows (c_select = the bitmap of grad_pre) and a
-            # GEMM over them replace the transpose product and the full-height GEMM
+            # GEMM over them replace the transpose product and the full-height GEMM.  The
+            # product here gathers rows of width Fin where the transpose product gathers width
+            # Fout, and z is [n_rows, Fin]: it pays (and is bounded in memory) only while Fin is
+            # not much wider than Fout — a 1433 -> 16 layer keeps the transpose product.
             z = spmm_csr(ctx.graph, input, tag="bwd", c_select=hint[0],
-                         out=_maybe_poisoned((n, input.shape[1]), input.dtype, input.device))
+                         out=_maybe_poisoned((ctx.graph.shape[0], input.shape[1]), input.dtype,
+                                             input.device))
             rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
             grad_w = _weight_grad(z.index_select(0, rows), grad_pre.index_select(0, rows))
             return None, grad_w, grad_bias, None, None, None, None, None
@@ -526,5 +546,7 @@ class GraphConvFunction(torch.autograd.Function):
 
 
 def spmm(adj, dense, bias=None):
-    """Drop-in for `torch.spmm(adj, dense)` (+ optional fused bias) with autograd."""
-    return SpMMFunction.apply(as_graph(adj), dense, bias)
+    """Drop-in for `torch.spmm(adj, dense)` (+ optional fused bias) with autograd: a thin caller
+    of the registered operator `torch.ops.pygcn_amd.spmm_csr` (pygcn_amd/ops.py)."""
+    from .ops import sparse_mm
+    return sparse_mm(adj, dense, bias)

@@ -98,14 +98,18 @@ def load_data(path=DEFAULT_CORA, dataset="cora"):
 
 
 # ------------------------------------------------------------------ synthetic graphs (C3-C5)
-def rmat_edges(n, n_edges, seed=42, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu"):
-    """`n_edges` directed R-MAT pairs over `n` vertices (ids >= n rejected), as int64 tensors."""
+def rmat_edge_chunks(n, n_edges, seed=42, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu"):
+    """Generator over the stream of `n_edges` directed R-MAT pairs (ids >= n rejected) in chunks
+    of at most 2^27 candidates: yields (src, dst) int64 tensors.  The stream depends on
+    (n, n_edges, seed, device type) only, so every process that iterates it sees the same edges —
+    a rank of the sharded path keeps the pairs it owns from each chunk and drops the rest, holding
+    O(chunk) + O(nnz / ranks) memory instead of the whole edge list."""
     device = torch.device(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     scale = max(1, int(np.ceil(np.log2(max(n, 2)))))
     a, b, c, _ = abcd
-    src_parts, dst_parts, have = [], [], 0
+    have = 0
     while have < n_edges:
         m = int(min(max((n_edges - have) * 1.3 + 1024, 1024), 2 ** 27))
         src = torch.zeros(m, dtype=torch.int64, device=device)
@@ -118,10 +122,54 @@ def rmat_edges(n, n_edges, seed=42, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu")
             dst = (dst << 1) | dbit
         ok = (src < n) & (dst < n)
         src, dst = src[ok], dst[ok]
-        src_parts.append(src)
-        dst_parts.append(dst)
-        have += int(src.numel())
-    return torch.cat(src_parts)[:n_edges], torch.cat(dst_parts)[:n_edges]
+        take = min(int(src.numel()), n_edges - have)
+        have += take
+        yield src[:take], dst[:take]
+
+
+def rmat_edges(n, n_edges, seed=42, abcd=(0.57, 0.19, 0.19, 0.05), device="cpu"):
+    """`n_edges` directed R-MAT pairs over `n` vertices (ids >= n rejected), as int64 tensors."""
+    parts = list(rmat_edge_chunks(n, n_edges, seed, abcd, device))
+    return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+
+
+def vertex_permutation(n, perm_seed, device):
+    """The seeded vertex relabelling of the synthetic graphs (breaks id/degree correlation)."""
+    gen = torch.Generator(device=torch.device(device))
+    gen.manual_seed(perm_seed)
+    return torch.randperm(n, generator=gen, device=device)
+
+
+def rmat_row_block(n, n_edges, r0, r1, seed=42, perm_seed=43, device="cpu", counts_only=False):
+    """Rows [r0, r1) of the SAME normalized adjacency `rmat_graph(n, n_edges, seed, perm_seed)`
+    builds, generated without ever holding the other rows: the edge stream is replayed chunk by
+    chunk and only pairs whose (relabelled) source lies in the block are kept.  Returns
+    (rowptr rebased to 0, col global ids int32, val fp32); with `counts_only` just the stored
+    entries per row (int64 [r1 - r0]) — all a partitioner needs."""
+    device = torch.device(device)
+    perm = vertex_permutation(n, perm_seed, device) if perm_seed is not None else None
+    keys = []
+    for src, dst in rmat_edge_chunks(n, n_edges, seed, device=device):
+        if perm is not None:
+            src, dst = perm[src], perm[dst]
+        keep = (src >= r0) & (src < r1)
+        keys.append(torch.unique((src[keep] - r0) * n + dst[keep]))   # (chunk-local dedupe)
+    del perm
+    diag = torch.arange(r0, r1, device=device, dtype=torch.int64)
+    key = torch.unique(torch.cat(keys + [(diag - r0) * n + diag]))
+    del keys
+    row = key // n
+    deg = torch.bincount(row, minlength=r1 - r0)
+    if counts_only:
+        return deg
+    col = (key - row * n).to(torch.int32)
+    del key
+    rowptr = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    val = (1.0 / deg.to(torch.float32))[row]
+    if col.numel() < 2 ** 31 - 1:
+        rowptr = rowptr.to(torch.int32)
+    return rowptr, col, val
 
 
 def normalized_adjacency_csr(src, dst, n, perm_seed=43):

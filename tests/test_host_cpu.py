@@ -174,7 +174,7 @@ def test_load_data_reproduces_reference_adjacency():
 
 def test_product_refuses_cpu_tensors():
     """No CPU fallback: the layer and the op raise on non-HIP tensors."""
-    from pygcn_amd import GraphConvolution, spmm
+    from pygcn_amd import GraphConvolution, sparse_mm as spmm
     layer = GraphConvolution(4, 3)
     adj = torch.eye(5).to_sparse()
     with pytest.raises(RuntimeError, match="HIP device"):
@@ -218,3 +218,34 @@ def test_ctypes_structs_follow_the_header_field_by_field():
             fields.append((m.group(3), 8 if m.group(2) else width[m.group(1)]))
         got = [(n, ctypes.sizeof(t)) for n, t in mirror._fields_]
         assert got == fields, (cname, got, fields)
+
+
+def test_registered_operator_surface():
+    """the product is a registered PyTorch operator with an autograd formula, a
+    fake (meta) kernel for tracing, and NO CPU kernel that computes anything."""
+    import pygcn_amd  # noqa: F401  (registers the operator)
+    op = torch.ops.pygcn_amd.spmm_csr
+    schema = str(op.default._schema)
+    assert "Tensor rowptr" in schema and "Tensor? bias" in schema and "n_cols" in schema
+    rp = torch.tensor([0, 1, 3], dtype=torch.int32)
+    col = torch.tensor([0, 0, 1], dtype=torch.int32)
+    val = torch.ones(3)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        op(rp, col, val, torch.randn(2, 4), None, 2)
+    # shape inference without any kernel running (what torch.compile traces through)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        out = op(torch.empty(6, dtype=torch.int32), torch.empty(9, dtype=torch.int32),
+                 torch.empty(9), torch.empty(7, 16), None, 7)
+        assert tuple(out.shape) == (5, 16) and out.dtype == torch.float32
+        with pytest.raises(RuntimeError, match="size mismatch"):
+            op(torch.empty(6, dtype=torch.int32), torch.empty(9, dtype=torch.int32),
+               torch.empty(9), torch.empty(8, 16), None, 7)
+
+
+def test_package_exports_module_not_shadowed():
+    """`pygcn_amd.spmm` is the module (a re-exported function used to shadow it)."""
+    import types
+    import pygcn_amd
+    assert isinstance(pygcn_amd.spmm, types.ModuleType)
+    assert callable(pygcn_amd.sparse_mm) and callable(pygcn_amd.spmm.spmm)

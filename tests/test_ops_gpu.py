@@ -1,0 +1,112 @@
+"""The registered operator `torch.ops.pygcn_amd.spmm_csr` and the reference-surface
+CLI `pygcn_amd/train.py` (reference pygcn/train.py:36-51,134-166) on the GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from conftest import ROOT, assert_normwise, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from pygcn_amd import _native
+    _native.lib()
+    return torch.device("cuda:0")
+
+
+def _csr(oracle, n_rows, n_cols, seed):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(6, size=n_rows)
+    deg[3] = 700                                  # one long row (chunked path)
+    deg[rng.integers(0, n_rows, 15)] = 0
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = rng.integers(0, n_cols, size=int(rowptr[-1])).astype(np.int32)
+    val = (1.0 - rng.random(len(col))).astype(np.float32)
+    return oracle.CSR(rowptr, col, val, (n_rows, n_cols))
+
+
+@pytest.mark.parametrize("F,relu,bias", [(256, False, True), (16, True, True), (7, False, False)])
+def test_operator_matches_oracle_forward_and_backward(oracle, dev, F, relu, bias):
+    a = _csr(oracle, 500, 420, seed=60 + F)       # rectangular: A is [500, 420]
+    rp = torch.from_numpy(a.rowptr.astype(np.int32)).to(dev)
+    col, val = torch.from_numpy(a.col).to(dev), torch.from_numpy(a.val).to(dev)
+    B = gin.dense((420, F), 61)
+    b = gin.dense((F,), 62) if bias else None
+    go = gin.dense((500, F), 63)
+    Bt = torch.from_numpy(B).to(dev).requires_grad_(True)
+    bt = torch.from_numpy(b).to(dev).requires_grad_(True) if bias else None
+    out = torch.ops.pygcn_amd.spmm_csr(rp, col, val, Bt, bt, 420, relu)
+    out.backward(torch.from_numpy(go).to(dev))
+    ref = oracle.spmm_csr(a.rowptr, a.col, a.val, B)
+    if bias:
+        ref = ref + b
+    gpre = go
+    if relu:
+        gpre = np.where(ref > 0, go, 0).astype(np.float32)
+        ref = np.maximum(ref, 0)
+    assert_normwise(out.detach().cpu(), ref, TOL, "A·B")
+    assert_normwise(Bt.grad.cpu(), oracle.spmm_csr_t(a.rowptr, a.col, a.val, gpre, 420), TOL,
+                    "Aᵀ·grad")
+    if bias:
+        assert_normwise(bt.grad.cpu(), gpre.sum(0, dtype=np.float64), 2e-5, "grad_bias")
+    # the schedule and the transpose were built once for these arrays and are reused
+    from pygcn_amd.graph import graph_for_arrays
+    g = graph_for_arrays(rp, col, val, (500, 420))
+    assert g is graph_for_arrays(rp, col, val, (500, 420)) and g._plan is not None
+    assert g._t is not None and g.t() is g._t
+
+
+def test_operator_passes_opcheck_and_traces(oracle, dev):
+    a = _csr(oracle, 300, 300, seed=70)
+    rp = torch.from_numpy(a.rowptr.astype(np.int32)).to(dev)
+    col, val = torch.from_numpy(a.col).to(dev), torch.from_numpy(a.val).to(dev)
+    B = torch.from_numpy(gin.dense((300, 64), 71)).to(dev).requires_grad_(True)
+    bias = torch.from_numpy(gin.dense((64,), 72)).to(dev).requires_grad_(True)
+    torch.library.opcheck(torch.ops.pygcn_amd.spmm_csr.default, (rp, col, val, B, bias, 300, False),
+                          test_utils=("test_schema", "test_autograd_registration",
+                                      "test_faketensor"))
+    # through AOT autograd (the operator's fake kernel + registered backward, no Triton needed)
+    def f(B, bias):
+        return torch.ops.pygcn_amd.spmm_csr(rp, col, val, B, bias, 300, False).square().sum()
+    eager = f(B, bias)
+    ge = torch.autograd.grad(eager, (B, bias))
+    traced = torch.compile(f, backend="aot_eager")(B, bias)
+    gt = torch.autograd.grad(traced, (B, bias))
+    assert torch.allclose(eager, traced, rtol=1e-6)
+    for x, y in zip(ge, gt):
+        assert torch.equal(x, y)
+
+
+def test_train_script_runs_like_the_reference_cli(dev):
+    """`cd pygcn_amd && python train.py` — the reference's usage (pygcn/train.py:36-51: same
+    flags) — for 5 epochs without dropout: the printed loss / accuracy fields are those of G5, the
+    trajectory captured from the imported reference layer (--fastmode: validation on the training
+    pass's output, which is how G5's loss_val was taken)."""
+    g5 = load_golden("g5_trajectory.npz")
+    r = subprocess.run([sys.executable, "train.py", "--epochs", "5", "--dropout", "0", "--fastmode"],
+                       cwd=os.path.join(ROOT, "pygcn_amd"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = re.findall(r"Epoch: (\d+) loss_train: ([\d.]+) acc_train: ([\d.]+) loss_val: ([\d.]+) "
+                      r"acc_val: ([\d.]+) time: [\d.]+s", r.stdout)
+    assert [int(x[0]) for x in rows] == [1, 2, 3, 4, 5], r.stdout[-2000:]
+    got = np.array([[float(v) for v in x[1:4]] for x in rows])
+    np.testing.assert_allclose(got[:, 0], g5["loss_train"][:5], atol=1.5e-4)   # printed with %.4f
+    np.testing.assert_allclose(got[:, 1], g5["acc_train"][:5], atol=1.5e-4)
+    np.testing.assert_allclose(got[:, 2], g5["loss_val"][:5], atol=1.5e-4)
+    assert "Optimization Finished!" in r.stdout and "Test set results:" in r.stdout
+    # default flags (dropout 0.5, validation re-evaluated in eval mode) also run to the end
+    r = subprocess.run([sys.executable, "train.py", "--epochs", "3"],
+                       cwd=os.path.join(ROOT, "pygcn_amd"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and r.stdout.count("Epoch:") == 3, r.stderr[-2000:]

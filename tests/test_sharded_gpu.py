@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, n_edges, out_dir, exchange):
+def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -30,35 +30,19 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
     from pygcn_amd.sharded import ShardedGCN, ShardedGraph
     from pygcn_amd.utils import rmat_graph
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # stage device tensors through the host for gloo (rehearsal only)
-    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
-
-    def ag(out, inp, group=None):
-        o, i = out.cpu(), inp.cpu()
-        real_ag(o, i, group=group)
-        out.copy_(o)
-
-    def ar(t, op=dist.ReduceOp.SUM, group=None):
-        c = t.cpu()
-        real_ar(c, op=op, group=group)
-        t.copy_(c)
-    dist.all_gather_into_tensor, dist.all_reduce = ag, ar
-    import pygcn_amd.sharded as sh
-    real_p2p = sh._p2p_round
-
-    def p2p(sends, recvs, group):   # grouped isend/irecv staged through the host
-        hs = [(t.cpu(), peer) for t, peer in sends]
-        hr = [(torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
-        real_p2p(hs, hr, group)
-        for (t, _), (h, _) in zip(recvs, hr):
-            t.copy_(h)
-    sh._p2p_round = p2p
+    from pygcn_amd._rehearsal import install_host_staging
+    install_host_staging()      # gloo moves host memory: stage device tensors through the host
     try:
         dev = torch.device("cuda:0")
         F = 256
-        rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")
-        sg = ShardedGraph.from_global_csr(rowptr.to(dev), col.to(dev), val.to(dev), n, rank, world,
-                                          exchange=exchange)
+        if build == "global":
+            rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")
+            sg = ShardedGraph.from_global_csr(rowptr.to(dev), col.to(dev), val.to(dev), n, rank,
+                                              world, exchange=exchange)
+        else:   # shard-local: each rank generates its own rows on the device, Âᵀ by triplet exchange
+            sg = ShardedGraph.from_rmat(n, n_edges, rank, world, dev, seed=5, exchange=exchange)
+            rowptr, col, val = rmat_graph(n, n_edges, seed=5, device=dev)   # (reference only)
+        assert sg.overlap == (exchange == "halo")
         recv, full = sg.exchange_rows()
         assert (recv < 0.8 * full) if exchange == "halo" else recv == full
         x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, F)).astype(np.float32))
@@ -94,10 +78,72 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["halo", "allgather"])
-def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, exchange):
+@pytest.mark.parametrize("exchange,build", [("halo", "global"), ("allgather", "global"),
+                                            ("halo", "local")])
+def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, exchange, build):
     assert torch.cuda.is_available()
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), 60000, 600000, str(tmp_path), exchange), nprocs=2,
-             join=True)
+    mp.spawn(_worker, args=(2, _free_port(), 60000, 600000, str(tmp_path), exchange, build),
+             nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _nccl_worker(rank, world, port, n, n_edges, out_dir):
+    """The sharded path on the REAL backend (RCCL), world size 1 — the only RCCL execution a
+    one-GPU box allows: communicator init bound to the device, all_gather_into_tensor (degree
+    counts, halo count matrix, row all-gather), all_reduce (loss count, gradient bucket), barrier,
+    and the zero-peer point-to-point rounds, end to end against the plain single-GPU model."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.sharded import ShardedGCN, ShardedGraph
+    from pygcn_amd.utils import rmat_graph
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        F = 256
+        rowptr, col, val = rmat_graph(n, n_edges, seed=5, device=dev)
+        x = torch.randn(n, F, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+        labels = torch.randint(0, F, (n,), device=dev,
+                               generator=torch.Generator(device=dev).manual_seed(2))
+        idx = torch.arange(n // 20, device=dev)
+        torch.manual_seed(42)
+        ref = GCN(F, F, F, dropout=0.0).to(dev)
+        ref.train()
+        g = CSRGraph(rowptr, col, val, (n, n))
+        rl = ref(x, g)
+        rloss = torch.nn.functional.nll_loss(rl[idx], labels[idx])
+        rloss.backward()
+        for exchange in ("halo", "allgather"):
+            sg = ShardedGraph.from_rmat(n, n_edges, rank, world, dev, seed=5, exchange=exchange)
+            assert sg.bounds == [0, n] and sg.nnz_local == int(col.numel())
+            assert torch.equal(sg.At.col, g.t().col) and torch.equal(sg.At.val, g.t().val)
+            torch.manual_seed(42)
+            model = GCN(F, F, F, dropout=0.0).to(dev)
+            smodel = ShardedGCN(model, sg)
+            model.train()
+            logp = smodel(x, sg)
+            loss = smodel.nll_loss(logp, labels, idx)
+            loss.backward()
+            smodel.allreduce_grads()
+            dist.barrier()
+            assert abs(smodel.global_loss(loss) - rloss.item()) <= 1e-5 * abs(rloss.item())
+            err = (logp - rl).abs().max().item()
+            assert err <= 1e-5 * rl.abs().max().item(), (exchange, err)
+            for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+                e = (p.grad - q.grad).abs().max().item()
+                assert e <= 2e-5 * q.grad.abs().max().item(), (exchange, k, e)
+        open(os.path.join(out_dir, "ok_nccl"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_path_on_rccl_world_size_one(tmp_path):
+    assert torch.cuda.is_available()
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_worker, args=(1, _free_port(), 60000, 600000, str(tmp_path)), nprocs=1, join=True)
+    assert os.listdir(tmp_path) == ["ok_nccl"]

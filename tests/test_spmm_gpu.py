@@ -37,7 +37,7 @@ def _graph(oracle_csr, dev, **kw):
 # ------------------------------------------------------------------ golden edge cases
 @pytest.mark.parametrize("case", EDGE_CASES, ids=[c[0] for c in EDGE_CASES])
 def test_layer_matches_reference_golden(oracle, dev, case):
-    from pygcn_amd import GraphConvolution, spmm
+    from pygcn_amd import GraphConvolution, sparse_mm as spmm
     g4 = load_golden("g4_edge_cases.npz")
     k = EDGE_CASES.index(case)
     name, nr, nc, nnz, fin, fout, bias, kw = case
@@ -464,29 +464,38 @@ def test_randomized_shapes_and_schedules(oracle, dev):
 
 
 def test_bf16_model_end_to_end(oracle, dev):
-    """Config C5 numerics through the whole layer stack: bf16 parameters / activations, fp32
-    adjacency values and accumulation; forward and backward stay within bf16 rounding of the fp32
-    run (2^-6 normwise on activations after two layers, 2^-4 on gradients)."""
+    """Config C5 numerics through the whole layer stack against the ORACLE: the bf16 model
+    (bf16 parameters / activations, fp32 adjacency values and accumulation) is compared with the
+    oracle's fp32 forward / loss / backward (`gcn2_loss_backward`) run on the SAME bf16-rounded
+    parameters and inputs.  What differs is only the storage rounding of the intermediate
+    activations and gradients (support, hidden layer, log-probabilities: one rounding each), so the
+    gates are a few bf16 ulps: 2^-6 normwise on the log-probabilities after two layers, 2^-4 on
+    the parameter gradients (bf16 is outside the 1e-5 contract)."""
     from pygcn_amd import GCN, CSRGraph
     from pygcn_amd.utils import rmat_graph
     n, F = 20000, 128
     rowptr, col, val = rmat_graph(n, 200000, seed=3, device="cpu")
     g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
-    x = torch.from_numpy(gin.dense((n, F), 1)).to(dev)
-    y = torch.from_numpy(np.random.default_rng(2).integers(0, F, n)).to(dev)
+    x16 = torch.from_numpy(gin.dense((n, F), 1)).to(torch.bfloat16)
+    y = np.random.default_rng(2).integers(0, F, n)
+    idx = np.arange(n // 10)
     torch.manual_seed(5)
-    m32 = GCN(F, F, F, dropout=0.0).to(dev)
-    m16 = GCN(F, F, F, dropout=0.0).to(dev).to(torch.bfloat16)
-    m16.load_state_dict({k: v.to(torch.bfloat16) for k, v in m32.state_dict().items()})
-    out32 = m32(x, g)
-    out16 = m16(x.to(torch.bfloat16), g)
+    m16 = GCN(F, F, F, dropout=0.0).to(torch.bfloat16).to(dev)
+    out16 = m16(x16.to(dev), g)
     assert out16.dtype == torch.bfloat16
-    torch.nn.functional.nll_loss(out32, y).backward()
-    torch.nn.functional.nll_loss(out16.float(), y).backward()
-    assert_normwise(out16.float().detach().cpu(), out32.detach().cpu().numpy(), 2.0 ** -6, "logp")
-    for (k, p16), (_, p32) in zip(m16.named_parameters(), m32.named_parameters()):
-        assert p16.grad.dtype == torch.bfloat16
-        assert_normwise(p16.grad.float().cpu(), p32.grad.cpu().numpy(), 2.0 ** -4, k + ".grad")
+    idx_t = torch.from_numpy(idx).to(dev)
+    loss = torch.nn.functional.nll_loss(out16[idx_t].float(), torch.from_numpy(y).to(dev)[idx_t])
+    loss.backward()
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    p = {k: v.detach().float().cpu().numpy() for k, v in m16.state_dict().items()}   # bf16-rounded
+    ref_loss, fw, grads, _ = oracle.gcn2_loss_backward(x16.float().numpy(), a, p, y, idx)
+    assert_normwise(out16.float().detach().cpu(), fw["logp"], 2.0 ** -6, "logp")
+    assert abs(loss.item() - ref_loss) <= 2.0 ** -6 * abs(ref_loss)
+    for k, v in grads.items():
+        mod, name = k.split(".")
+        got = getattr(getattr(m16, mod), name).grad
+        assert got.dtype == torch.bfloat16
+        assert_normwise(got.float().cpu(), v, 2.0 ** -4, k + ".grad")
 
 
 @pytest.mark.parametrize("idx64", [False, True])
