@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 12
+#define GCN_ABI_VERSION 13
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -99,6 +99,29 @@ int gcn_plan_fill_host(const void *rowptr_host, int rowptr_is64, int64_t n_rows,
                        int32_t item_cost, int32_t long_thresh, int32_t *items, int64_t n_items,
                        int32_t *chunk_row, int64_t *chunk_e0, int64_t n_chunks,
                        int32_t *long_row, int32_t *long_chunk0, int64_t n_long);
+
+/*
+ * The same planner ON THE DEVICE: rowptr is a DEVICE array and never visits
+ * the host; the result equals gcn_plan_{count,fill}_host array for array.  Two calls around one
+ * 24-byte read:
+ *   gcn_plan_count_device  computes the schedule into `workspace` and writes
+ *                          counts[0..2] = (n_items, n_chunks, n_long) to DEVICE memory;
+ *   (the caller copies the three counts to the host and allocates the plan arrays on the device)
+ *   gcn_plan_fill_device   writes items[2*n_items], chunk_row[n_chunks], chunk_e0[n_chunks],
+ *                          long_row[n_long], long_chunk0[n_long+1] (DEVICE arrays) from the
+ *                          workspace gcn_plan_count_device left behind (same stream / ordered).
+ * Greedy segmentation in parallel: per-row item ends by binary search in scanned row costs, item
+ * starts by pointer doubling over "next item start" (pygcn_amd/csrc/gcn_plan.hip).  Scratch:
+ * gcn_plan_device_workspace_bytes(n_rows) (48 B per row + scan temporaries).
+ */
+size_t gcn_plan_device_workspace_bytes(int64_t n_rows);
+int gcn_plan_count_device(const void *rowptr, int rowptr_is64, int64_t n_rows, int32_t item_cost,
+                          int32_t long_thresh, void *workspace, size_t workspace_bytes,
+                          int64_t *counts, void *stream);
+int gcn_plan_fill_device(const void *rowptr, int rowptr_is64, int64_t n_rows, int32_t long_thresh,
+                         const void *workspace, size_t workspace_bytes, int32_t *items,
+                         int64_t n_items, int32_t *chunk_row, int64_t *chunk_e0, int64_t n_chunks,
+                         int32_t *long_row, int32_t *long_chunk0, int64_t n_long, void *stream);
 
 /* Bytes of DEVICE scratch gcn_spmm_csr() needs for feature width F (0 if no long rows). */
 size_t gcn_spmm_workspace_bytes(const gcn_csr_plan *plan, int64_t F);
@@ -252,6 +275,27 @@ int gcn_csr_transpose_device(const void *rowptr, int rowptr_is64, const int32_t 
                              const float *val, int64_t n_rows, int64_t n_cols, int64_t nnz,
                              void *rowptr_t, int32_t *col_t, float *val_t, void *workspace,
                              size_t workspace_bytes, void *stream);
+
+/*
+ * COO -> CSR on the DEVICE with duplicate reduction: the adjacency construction of the reference's
+ * data recipe (pygcn/utils.py:360-368: scipy `coo_matrix(...)`, symmetrization, `+ I`) and of
+ * `sparse_mx_to_torch_sparse_tensor` consumers (utils.py:407-414: int64 [2, nnz] indices, fp32
+ * values, uncoalesced).  Entries may come in any order; entries with the same (row, col) are
+ * reduced IN STORAGE ORDER with
+ *   GCN_REDUCE_SUM  what scipy's coo->csr conversion and torch.spmm on an uncoalesced tensor do;
+ *   GCN_REDUCE_MAX  elementwise maximum — `adj + adj.T*(adj.T > adj) - adj*(adj.T > adj)`
+ *                   (utils.py:365) is max(adj, adj.T), i.e. MAX over the entries of adj and adj.T.
+ * Outputs: rowptr_out[n_rows+1] (int32 or int64), col_out / val_out with capacity nnz (sorted by
+ * column inside every row), *nnz_out (DEVICE) = number of distinct entries.  All pointers DEVICE;
+ * the caller guarantees 0 <= row < n_rows, 0 <= col < n_cols.  Deterministic, no atomics.
+ */
+#define GCN_REDUCE_SUM 0
+#define GCN_REDUCE_MAX 1
+size_t gcn_coo_to_csr_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz);
+int gcn_coo_to_csr_device(const int64_t *row, const int64_t *col, const float *val, int64_t nnz,
+                          int64_t n_rows, int64_t n_cols, int reduce, void *rowptr_out,
+                          int rowptr_is64, int32_t *col_out, float *val_out, int64_t *nnz_out,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * val <- D^-1 · val in place on the DEVICE: every stored entry is divided by the sum of its row;

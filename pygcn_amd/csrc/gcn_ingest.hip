@@ -108,6 +108,93 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const IdxT *__restri
     }
 }
 
+// ---- COO -> CSR with duplicate reduction (pygcn/utils.py:360-368 on the device) ----------------
+// key = row * n_cols + col of every stored entry; a stable radix sort of (key, storage position)
+// puts duplicates next to each other IN STORAGE ORDER; the head of every run reduces its run
+// sequentially (sum: what scipy's coo->csr and torch.spmm on an uncoalesced COO tensor do; max: the
+// elementwise maximum the reference's symmetrization `adj + adj.T*(adj.T > adj) - adj*(adj.T > adj)`
+// amounts to), so the result does not depend on thread scheduling.  No atomics.
+__global__ __launch_bounds__(256) void coo_keys_kernel(const int64_t *__restrict__ row,
+                                                       const int64_t *__restrict__ col, int64_t nnz,
+                                                       int64_t n_cols, uint64_t *__restrict__ key,
+                                                       uint32_t *__restrict__ pos)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
+        key[e] = (uint64_t)row[e] * (uint64_t)n_cols + (uint64_t)col[e];
+        pos[e] = (uint32_t)e;
+    }
+}
+
+__global__ __launch_bounds__(256) void coo_heads_kernel(const uint64_t *__restrict__ key, int64_t nnz,
+                                                        int64_t *__restrict__ head)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e <= nnz; e += stride)
+        head[e] = (e < nnz && (e == 0 || key[e] != key[e - 1])) ? 1 : 0;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void coo_reduce_kernel(const uint64_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ pos,
+                                                         const int64_t *__restrict__ outpos,
+                                                         const float *__restrict__ val, int64_t nnz,
+                                                         int64_t n_rows, int64_t n_cols, int reduce_max,
+                                                         IdxT *__restrict__ rowptr,
+                                                         int32_t *__restrict__ col_out,
+                                                         float *__restrict__ val_out,
+                                                         int64_t *__restrict__ nnz_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t e = tid; e < nnz; e += stride) {
+        const uint64_t k = key[e];
+        if (e > 0 && key[e - 1] == k) continue;             // not the head of its run
+        float acc = val[pos[e]];
+        for (int64_t j = e + 1; j < nnz && key[j] == k; ++j) {
+            const float v = val[pos[j]];
+            acc = reduce_max ? fmaxf(acc, v) : acc + v;
+        }
+        const int64_t o = outpos[e];
+        col_out[o] = (int32_t)(k % (uint64_t)n_cols);
+        val_out[o] = acc;
+    }
+    // rowptr[r] = number of distinct keys below r * n_cols
+    for (int64_t r = tid; r <= n_rows; r += stride) {
+        const uint64_t bound = (uint64_t)r * (uint64_t)n_cols;
+        int64_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (key[mid] < bound)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        rowptr[r] = (IdxT)outpos[lo];
+    }
+    if (tid == 0) *nnz_out = outpos[nnz];
+}
+
+int key_bits64(int64_t n_rows, int64_t n_cols)
+{
+    const unsigned __int128 top = (unsigned __int128)n_rows * (unsigned __int128)n_cols;
+    int b = 1;
+    while (b < 64 && ((unsigned __int128)1 << b) < top) ++b;
+    return b;
+}
+
+size_t coo_sort_temp_bytes(int64_t nnz, int bits)
+{
+    size_t temp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t *)nullptr,
+                                             (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, nnz, 0, bits, (hipStream_t)0);
+    size_t scan = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (int64_t *)nullptr, (int64_t *)nullptr,
+                                           nnz + 1, (hipStream_t)0);
+    return temp > scan ? temp : scan;
+}
+
 size_t sort_temp_bytes(int64_t nnz, int bits)
 {
     size_t temp = 0;
@@ -173,6 +260,73 @@ int gcn_csr_transpose_device(const void *rowptr, int rowptr_is64, const int32_t 
                            keys_sorted, n_cols, nnz, (int32_t *)rowptr_t, col_t, val_t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ifail_hip(e, "gcn_csr_transpose_device: launch");
+    return 0;
+}
+
+size_t gcn_coo_to_csr_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz)
+{
+    if (nnz <= 0) return 256;
+    return 2 * align_up((size_t)nnz * 8) + 2 * align_up((size_t)nnz * 4) +
+           align_up(((size_t)nnz + 1) * 8) +
+           align_up(coo_sort_temp_bytes(nnz, key_bits64(n_rows, n_cols))) + 256;
+}
+
+int gcn_coo_to_csr_device(const int64_t *row, const int64_t *col, const float *val, int64_t nnz,
+                          int64_t n_rows, int64_t n_cols, int reduce, void *rowptr_out,
+                          int rowptr_is64, int32_t *col_out, float *val_out, int64_t *nnz_out,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n_rows < 0 || n_cols < 0 || nnz < 0 || n_rows >= INT32_MAX || n_cols >= INT32_MAX ||
+        nnz >= (int64_t)UINT32_MAX || rowptr_out == nullptr || nnz_out == nullptr ||
+        (reduce != GCN_REDUCE_SUM && reduce != GCN_REDUCE_MAX))
+        return ifail(GCN_E_BADARG, "gcn_coo_to_csr_device: bad sizes / NULL outputs / unknown reduce");
+    if (nnz > 0 && (row == nullptr || col == nullptr || val == nullptr || col_out == nullptr ||
+                    val_out == nullptr))
+        return ifail(GCN_E_BADARG, "gcn_coo_to_csr_device: NULL entry arrays");
+    if (!rowptr_is64 && nnz >= INT32_MAX)
+        return ifail(GCN_E_BADARG, "gcn_coo_to_csr_device: int32 row pointers need nnz < 2^31");
+    if (workspace == nullptr || workspace_bytes < gcn_coo_to_csr_workspace_bytes(n_rows, n_cols, nnz))
+        return ifail(GCN_E_WORKSPACE, "gcn_coo_to_csr_device: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (nnz == 0) {
+        e = hipMemsetAsync(rowptr_out, 0, (size_t)(n_rows + 1) * (rowptr_is64 ? 8 : 4), s);
+        if (e == hipSuccess) e = hipMemsetAsync(nnz_out, 0, sizeof(int64_t), s);
+        return e == hipSuccess ? 0 : ifail_hip(e, "gcn_coo_to_csr_device: memset");
+    }
+    char *w = (char *)workspace;
+    uint64_t *key_in = (uint64_t *)w;
+    w += align_up((size_t)nnz * 8);
+    uint64_t *key_sorted = (uint64_t *)w;
+    w += align_up((size_t)nnz * 8);
+    uint32_t *pos_in = (uint32_t *)w;
+    w += align_up((size_t)nnz * 4);
+    uint32_t *pos_sorted = (uint32_t *)w;
+    w += align_up((size_t)nnz * 4);
+    int64_t *outpos = (int64_t *)w;
+    w += align_up(((size_t)nnz + 1) * 8);
+    const int bits = key_bits64(n_rows, n_cols);
+    size_t temp = coo_sort_temp_bytes(nnz, bits);
+    const unsigned blocks = (unsigned)std::min<int64_t>((std::max<int64_t>(nnz, n_rows) + 256) / 256,
+                                                        256 * 32);
+    hipLaunchKernelGGL(coo_keys_kernel, dim3(blocks), dim3(256), 0, s, row, col, nnz, n_cols, key_in,
+                       pos_in);
+    e = hipcub::DeviceRadixSort::SortPairs((void *)w, temp, key_in, key_sorted, pos_in, pos_sorted,
+                                           nnz, 0, bits, s);
+    if (e != hipSuccess) return ifail_hip(e, "gcn_coo_to_csr_device: radix sort");
+    hipLaunchKernelGGL(coo_heads_kernel, dim3(blocks), dim3(256), 0, s, key_sorted, nnz, outpos);
+    e = hipcub::DeviceScan::ExclusiveSum((void *)w, temp, outpos, outpos, nnz + 1, s);
+    if (e != hipSuccess) return ifail_hip(e, "gcn_coo_to_csr_device: scan");
+    if (rowptr_is64)
+        hipLaunchKernelGGL(coo_reduce_kernel<int64_t>, dim3(blocks), dim3(256), 0, s, key_sorted,
+                           pos_sorted, outpos, val, nnz, n_rows, n_cols, reduce == GCN_REDUCE_MAX,
+                           (int64_t *)rowptr_out, col_out, val_out, nnz_out);
+    else
+        hipLaunchKernelGGL(coo_reduce_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, key_sorted,
+                           pos_sorted, outpos, val, nnz, n_rows, n_cols, reduce == GCN_REDUCE_MAX,
+                           (int32_t *)rowptr_out, col_out, val_out, nnz_out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return ifail_hip(e, "gcn_coo_to_csr_device: launch");
     return 0;
 }
 

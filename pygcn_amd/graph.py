@@ -99,34 +99,75 @@ class CSRGraph:
 
     # ------------------------------------------------------------------ constructors
     @classmethod
-    def from_coo(cls, row, col, val, shape, device=None, coalesced=False, **kw):
-        """COO triplets (any order, duplicates allowed — torch.spmm sums them) -> CSR."""
+    def from_coo(cls, row, col, val, shape, device=None, coalesced=False, reduce="sum", **kw):
+        """COO triplets (any order, duplicates allowed — torch.spmm sums them) -> CSR, on the
+        device by the native ingest primitive `gcn_coo_to_csr_device` (stable radix sort by
+        (row, col), duplicates reduced in storage order: deterministic, no atomics).
+        `reduce="max"` keeps the largest of duplicate entries instead of their sum (the
+        reference's symmetrization, see from_edge_list).  `coalesced` is accepted for
+        compatibility; sorted unique input simply sorts to itself."""
         row = torch.as_tensor(row)
         device = torch.device(device) if device is not None else row.device
-        row = row.to(device=device, dtype=torch.int64)
-        col = torch.as_tensor(col).to(device=device, dtype=torch.int64)
-        val = torch.as_tensor(val).to(device=device, dtype=torch.float32)
+        row = row.to(device=device, dtype=torch.int64).contiguous()
+        col = torch.as_tensor(col).to(device=device, dtype=torch.int64).contiguous()
+        val = torch.as_tensor(val).to(device=device, dtype=torch.float32).contiguous()
+        _require_cuda(row, "COO indices")
         n_rows, n_cols = int(shape[0]), int(shape[1])
-        if row.numel() and (int(row.max()) >= n_rows or int(col.max()) >= n_cols or
-                            int(row.min()) < 0 or int(col.min()) < 0):
+        nnz = int(row.numel())
+        if col.numel() != nnz or val.numel() != nnz:
+            raise RuntimeError("COO row / col / val must have the same length")
+        if nnz and (int(row.max()) >= n_rows or int(col.max()) >= n_cols or
+                    int(row.min()) < 0 or int(col.min()) < 0):
             raise RuntimeError("COO index out of range for the given shape")
-        if not coalesced and row.numel():
-            key = row * n_cols + col
-            key, perm = torch.sort(key, stable=True)
-            uniq, inv = torch.unique_consecutive(key, return_inverse=True)
-            if uniq.numel() != key.numel():   # sum duplicates in storage order
-                val = torch.zeros(uniq.numel(), dtype=torch.float32, device=device).index_add_(
-                    0, inv, val[perm])
-            else:
-                val = val[perm]
-            row, col = uniq // n_cols, uniq % n_cols
-        counts = torch.bincount(row, minlength=n_rows) if row.numel() else torch.zeros(
-            n_rows, dtype=torch.int64, device=device)
-        rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
-        torch.cumsum(counts, 0, out=rowptr[1:])
-        if row.numel() < 2 ** 31 - 1:
-            rowptr = rowptr.to(torch.int32)
-        return cls(rowptr, col.to(torch.int32), val, (n_rows, n_cols), **kw)
+        L = _native.lib()
+        is64 = int(nnz >= 2 ** 31 - 1)
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int64 if is64 else torch.int32, device=device)
+        col_out = torch.empty(nnz, dtype=torch.int32, device=device)
+        val_out = torch.empty(nnz, dtype=torch.float32, device=device)
+        nnz_out = torch.zeros(1, dtype=torch.int64, device=device)
+        ws_bytes = L.gcn_coo_to_csr_workspace_bytes(n_rows, n_cols, nnz)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            rc = L.gcn_coo_to_csr_device(
+                row.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, n_rows, n_cols,
+                {"sum": _native.GCN_REDUCE_SUM, "max": _native.GCN_REDUCE_MAX}[reduce],
+                rowptr.data_ptr(), is64, col_out.data_ptr(), val_out.data_ptr(), nnz_out.data_ptr(),
+                ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "gcn_coo_to_csr_device")
+        k = int(nnz_out.item())                     # one 8-byte read: the number of distinct entries
+        del ws
+        if k < nnz:                                 # give the unused capacity back
+            col_out, val_out = col_out[:k].clone(), val_out[:k].clone()
+        return cls(rowptr, col_out, val_out, (n_rows, n_cols), validate=False, **kw)
+
+    @classmethod
+    def from_edge_list(cls, edges, n, device="cuda", symmetrize=True, self_loops=True,
+                       normalize=True, **kw):
+        """The reference's adjacency recipe (pygcn/utils.py:360-368, kept there as a comment) on
+        the device, from an [E, 2] array of (source, target) vertex ids:
+            adj = coo_matrix(ones, (src, dst))                  duplicates SUMMED        :360-362
+            adj = adj + adj.T*(adj.T > adj) - adj*(adj.T > adj)  = max(adj, adj.T)       :365
+            adj = normalize(adj + I)                            D^-1 (A + I)            :368
+        Every step is the native COO->CSR reduction (sum / max) or the native row normalisation."""
+        dev = torch.device(device)
+        e = torch.as_tensor(edges).to(device=dev, dtype=torch.int64)
+        g = cls.from_coo(e[:, 0], e[:, 1], torch.ones(e.shape[0], device=dev), (n, n), **kw)
+        if symmetrize:
+            r, c, v = g.coo()
+            g = cls.from_coo(torch.cat([r, c]), torch.cat([c, r]), torch.cat([v, v]), (n, n),
+                             reduce="max", **kw)
+        if self_loops:
+            r, c, v = g.coo()
+            d = torch.arange(n, device=dev, dtype=torch.int64)
+            g = cls.from_coo(torch.cat([r, d]), torch.cat([c, d]),
+                             torch.cat([v, torch.ones(n, device=dev)]), (n, n), **kw)
+        return g.row_normalize_() if normalize else g
+
+    def coo(self):
+        """(row int64, col int64, val) of the stored entries, in CSR order."""
+        deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        row = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), deg)
+        return row, self.col.to(torch.int64), self.val
 
     @classmethod
     def from_torch(cls, adj, device=None, **kw):
@@ -157,9 +198,60 @@ class CSRGraph:
 
     # ------------------------------------------------------------------ schedule
     def plan(self):
-        """`struct gcn_csr_plan` for this matrix (built once, cached)."""
+        """`struct gcn_csr_plan` for this matrix (built once, cached) by the DEVICE planner
+        (`gcn_plan_count_device` / `gcn_plan_fill_device`): the row pointer never leaves HBM; the
+        only host transfer is the 24-byte read of (n_items, n_chunks, n_long)."""
         if self._plan is not None:
             return self._plan
+        if self._keep is None:
+            self._keep = self._plan_arrays_device()
+        keep = self._keep
+        ni, nc, nl = keep["n_items"], keep["n_chunks"], keep["n_long"]
+        p = _native.GcnCsrPlan()
+        p.n_rows, p.n_cols, p.nnz = self.shape[0], self.shape[1], self.nnz
+        p.rowptr, p.rowptr_is64 = self.rowptr.data_ptr(), int(self.rowptr.dtype == torch.int64)
+        p.long_thresh = self.long_thresh if self.long_thresh > 0 else \
+            _native.GCN_DEFAULT_LONG_THRESH
+        p.col, p.val = self.col.data_ptr(), self.val.data_ptr()
+        p.n_items, p.items = ni, keep["items"].data_ptr()
+        p.n_chunks, p.chunk_row, p.chunk_e0 = nc, keep["chunk_row"].data_ptr(), \
+            keep["chunk_e0"].data_ptr()
+        p.n_long, p.long_row, p.long_chunk0 = nl, keep["long_row"].data_ptr(), \
+            keep["long_chunk0"].data_ptr()
+        self._plan = p
+        return p
+
+    def _plan_arrays_device(self):
+        L = _native.lib()
+        dev, n_rows = self.device, self.shape[0]
+        is64 = int(self.rowptr.dtype == torch.int64)
+        ws_bytes = L.gcn_plan_device_workspace_bytes(n_rows)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        counts = torch.zeros(3, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            _native.check(L.gcn_plan_count_device(self.rowptr.data_ptr(), is64, n_rows,
+                                                  self.item_cost, self.long_thresh, ws.data_ptr(),
+                                                  ws_bytes, counts.data_ptr(), stream),
+                          "gcn_plan_count_device")
+            ni, nc, nl = (int(v) for v in counts.tolist())
+            keep = {"items": torch.empty(max(2 * ni, 1), dtype=torch.int32, device=dev),
+                    "chunk_row": torch.empty(max(nc, 1), dtype=torch.int32, device=dev),
+                    "chunk_e0": torch.empty(max(nc, 1), dtype=torch.int64, device=dev),
+                    "long_row": torch.empty(max(nl, 1), dtype=torch.int32, device=dev),
+                    "long_chunk0": torch.empty(nl + 1, dtype=torch.int32, device=dev),
+                    "n_items": ni, "n_chunks": nc, "n_long": nl}
+            _native.check(L.gcn_plan_fill_device(
+                self.rowptr.data_ptr(), is64, n_rows, self.long_thresh, ws.data_ptr(), ws_bytes,
+                keep["items"].data_ptr(), ni, keep["chunk_row"].data_ptr(),
+                keep["chunk_e0"].data_ptr(), nc, keep["long_row"].data_ptr(),
+                keep["long_chunk0"].data_ptr(), nl, stream), "gcn_plan_fill_device")
+        return keep
+
+    def plan_arrays_host_planner(self):
+        """The same schedule from the HOST planner (`gcn_plan_{count,fill}_host`), as numpy arrays
+        — kept for callers that hold the row pointer on the host, and as the cross-check of the
+        device planner (tests/test_ingest_gpu.py: array-for-array equality)."""
         L = _native.lib()
         rp_host = self.rowptr.cpu().numpy()
         is64 = int(self.rowptr.dtype == torch.int64)
@@ -179,24 +271,9 @@ class CSRGraph:
                                            chunk_row.ctypes.data, chunk_e0.ctypes.data, nc,
                                            long_row.ctypes.data, long_chunk0.ctypes.data, nl),
                       "gcn_plan_fill_host")
-        dev = self.device
-        keep = {k: torch.from_numpy(v).to(dev) for k, v in (
-            ("items", items), ("chunk_row", chunk_row), ("chunk_e0", chunk_e0),
-            ("long_row", long_row), ("long_chunk0", long_chunk0))}
-        p = _native.GcnCsrPlan()
-        p.n_rows, p.n_cols, p.nnz = n_rows, self.shape[1], self.nnz
-        p.rowptr, p.rowptr_is64 = self.rowptr.data_ptr(), is64
-        p.long_thresh = self.long_thresh if self.long_thresh > 0 else \
-            _native.GCN_DEFAULT_LONG_THRESH
-        p.col, p.val = self.col.data_ptr(), self.val.data_ptr()
-        p.n_items, p.items = ni, keep["items"].data_ptr()
-        p.n_chunks, p.chunk_row, p.chunk_e0 = nc, keep["chunk_row"].data_ptr(), \
-            keep["chunk_e0"].data_ptr()
-        p.n_long, p.long_row, p.long_chunk0 = nl, keep["long_row"].data_ptr(), \
-            keep["long_chunk0"].data_ptr()
-        self._keep = keep
-        self._plan = p
-        return p
+        return {"items": items[:2 * ni], "chunk_row": chunk_row[:nc], "chunk_e0": chunk_e0[:nc],
+                "long_row": long_row[:nl], "long_chunk0": long_chunk0,
+                "n_items": ni, "n_chunks": nc, "n_long": nl}
 
     def schedule_stats(self):
         p = self.plan()
@@ -244,6 +321,73 @@ class CSRGraph:
         _native.check(rc, "gcn_row_normalize_device")
         self._t = None
         return self
+
+    # ------------------------------------------------------------------ binary cache file
+    _PLAN_KEYS = ("items", "chunk_row", "chunk_e0", "long_row", "long_chunk0")
+
+    def save(self, path, with_transpose=True):
+        """Write CSR(Â), its schedule and (optionally) CSR(Âᵀ) + schedule to a versioned binary
+        cache file (pygcn_amd/cache.py).  Returns the file size in bytes."""
+        from . import cache
+        arrays = {}
+
+        def put(prefix, g):
+            g.plan()
+            k = g._keep
+            arrays[prefix + "rowptr"] = g.rowptr.cpu().numpy()
+            arrays[prefix + "col"] = g.col.cpu().numpy()
+            arrays[prefix + "val"] = g.val.cpu().numpy()
+            arrays[prefix + "items"] = k["items"][:2 * k["n_items"]].cpu().numpy()
+            arrays[prefix + "chunk_row"] = k["chunk_row"][:k["n_chunks"]].cpu().numpy()
+            arrays[prefix + "chunk_e0"] = k["chunk_e0"][:k["n_chunks"]].cpu().numpy()
+            arrays[prefix + "long_row"] = k["long_row"][:k["n_long"]].cpu().numpy()
+            arrays[prefix + "long_chunk0"] = k["long_chunk0"].cpu().numpy()
+        put("a.", self)
+        if with_transpose:
+            put("t.", self.t())
+        meta = {"n_rows": self.shape[0], "n_cols": self.shape[1], "nnz": self.nnz,
+                "item_cost": self.item_cost, "long_thresh": self.long_thresh,
+                "has_transpose": bool(with_transpose), "abi_version": _native.GCN_ABI_VERSION}
+        return cache.write_file(path, meta, arrays)
+
+    @classmethod
+    def load(cls, path, device="cuda", verify=True):
+        """Re-open a cache file written by save(): arrays go straight to the device; neither the
+        planner nor the transpose runs again."""
+        from . import cache
+        meta, arr = cache.read_file(path, verify=verify)
+        dev = torch.device(device)
+
+        def dev_t(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+        def get(prefix, shape):
+            g = cls(dev_t(arr[prefix + "rowptr"]), dev_t(arr[prefix + "col"]),
+                    dev_t(arr[prefix + "val"]), shape, item_cost=meta["item_cost"],
+                    long_thresh=meta["long_thresh"], validate=verify)
+            ni = arr[prefix + "items"].size // 2
+            nc, nl = arr[prefix + "chunk_row"].size, arr[prefix + "long_row"].size
+
+            def padded(name, dtype):      # (plan arrays are never empty tensors: 1 spare entry)
+                a = arr[prefix + name]
+                return dev_t(a) if a.size else torch.empty(1, dtype=dtype, device=dev)
+            g._keep = {"items": padded("items", torch.int32),
+                       "chunk_row": padded("chunk_row", torch.int32),
+                       "chunk_e0": padded("chunk_e0", torch.int64),
+                       "long_row": padded("long_row", torch.int32),
+                       "long_chunk0": dev_t(arr[prefix + "long_chunk0"]),
+                       "n_items": ni, "n_chunks": nc, "n_long": nl}
+            if g._keep["long_chunk0"].numel() != nl + 1:
+                raise cache.CacheFormatError(f"{path}: inconsistent schedule arrays")
+            return g
+        g = get("a.", (meta["n_rows"], meta["n_cols"]))
+        if g.nnz != meta["nnz"]:
+            raise cache.CacheFormatError(f"{path}: nnz in header and arrays differ")
+        if meta.get("has_transpose"):
+            gt = get("t.", (meta["n_cols"], meta["n_rows"]))
+            g._t, g._t_val_version = gt, g.val._version
+            gt._t, gt._t_val_version = g, gt.val._version
+        return g
 
     # ------------------------------------------------------------------ misc
     def to_torch_csr(self):

@@ -46,6 +46,29 @@ def _(rowptr, col, val, B, bias, n_cols, relu=False):
     return B.new_empty((rowptr.shape[0] - 1, B.shape[1]))
 
 
+@torch.library.custom_op("pygcn_amd::csr_transpose", mutates_args=(), device_types="cuda")
+def csr_transpose_op(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor,
+                     n_cols: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """CSR(Aᵀ) of the adjacency held in these arrays: (rowptr_T [n_cols+1], col_T, val_T), built by
+    the native device transpose (`gcn_csr_transpose_device`) the first time and cached with the
+    prepared adjacency — PyTorch re-derives the transposed operand on every backward call of
+    `torch.spmm`; here it is a lookup."""
+    gt = graph_for_arrays(rowptr, col, val, (rowptr.numel() - 1, n_cols)).t()
+    # (fresh tensor objects over the cached storage: an operator must not hand out its inputs or
+    #  the same Python object twice; nothing ever writes to these arrays)
+    return gt.rowptr.view(-1), gt.col.view(-1), gt.val.view(-1)
+
+
+@csr_transpose_op.register_kernel("cpu")
+def _(rowptr, col, val, n_cols):
+    raise RuntimeError(_NO_CPU.replace("spmm_csr", "csr_transpose"))
+
+
+@csr_transpose_op.register_fake
+def _(rowptr, col, val, n_cols):
+    return rowptr.new_empty((n_cols + 1,)), col.new_empty(col.shape), val.new_empty(val.shape)
+
+
 def _setup_context(ctx, inputs, output):
     rowptr, col, val, B, bias, n_cols, relu = inputs
     ctx.n_cols, ctx.relu = n_cols, bool(relu)
@@ -54,14 +77,15 @@ def _setup_context(ctx, inputs, output):
 
 
 def _backward(ctx, grad_out):
+    # written with operators only (no raw pointers), so AOT autograd can trace it
     rowptr, col, val = ctx.saved_tensors[:3]
     grad_B = grad_bias = None
     if ctx.relu:
-        grad_out = _spmm.relu_dropout_backward(grad_out.contiguous(), ctx.saved_tensors[3])
+        grad_out = torch.where(ctx.saved_tensors[3] > 0, grad_out, torch.zeros_like(grad_out))
     if ctx.needs_input_grad[3]:
-        gt = graph_for_arrays(rowptr, col, val, (rowptr.numel() - 1, ctx.n_cols)).t()
-        grad_B = torch.ops.pygcn_amd.spmm_csr(gt.rowptr, gt.col, gt.val, grad_out.contiguous(),
-                                              None, gt.shape[1], False)
+        rp_t, col_t, val_t = torch.ops.pygcn_amd.csr_transpose(rowptr, col, val, ctx.n_cols)
+        grad_B = torch.ops.pygcn_amd.spmm_csr(rp_t, col_t, val_t, grad_out.contiguous(), None,
+                                              rowptr.shape[0] - 1, False)
     if ctx.bias_dtype is not None and ctx.needs_input_grad[4]:
         grad_bias = grad_out.sum(0).to(ctx.bias_dtype)
     return None, None, None, grad_B, grad_bias, None, None

@@ -249,3 +249,36 @@ def test_package_exports_module_not_shadowed():
     import pygcn_amd
     assert isinstance(pygcn_amd.spmm, types.ModuleType)
     assert callable(pygcn_amd.sparse_mm) and callable(pygcn_amd.spmm.spmm)
+
+
+def test_cache_file_format_round_trip_and_rejections(tmp_path):
+    """pygcn_amd/cache.py (binary CSR cache): versioned, checksummed, pure host."""
+    from pygcn_amd import cache
+    rng = np.random.default_rng(0)
+    arrays = {"a.rowptr": np.arange(101, dtype=np.int32), "a.col": rng.integers(0, 100, 777).astype(np.int32),
+              "a.val": rng.random(777).astype(np.float32), "a.chunk_e0": np.arange(5, dtype=np.int64),
+              "a.long_row": np.empty(0, np.int32)}
+    path = str(tmp_path / "g.bin")
+    size = cache.write_file(path, {"n_rows": 100, "note": "x"}, arrays)
+    assert size == os.path.getsize(path)
+    meta, got = cache.read_file(path)
+    assert meta == {"n_rows": 100, "note": "x"} and list(got) == list(arrays)
+    for k, v in arrays.items():
+        assert got[k].dtype == v.dtype and np.array_equal(got[k], v), k
+    raw = bytearray(open(path, "rb").read())
+
+    def rejected(mutated, what):
+        p = str(tmp_path / "bad.bin")
+        open(p, "wb").write(bytes(mutated))
+        with pytest.raises(cache.CacheFormatError, match=what):
+            cache.read_file(p)
+    rejected(b"NOTACSR!" + raw[8:], "bad magic")
+    rejected(raw[:8] + (99).to_bytes(4, "little") + raw[12:], "format version 99")
+    rejected(raw[:len(raw) - 40], "outside the file")
+    import json
+    hlen = int.from_bytes(raw[12:16], "little")
+    sec = {x["name"]: x for x in json.loads(raw[16:16 + hlen].decode())["sections"]}
+    flipped = bytearray(raw)
+    flipped[sec["a.val"]["offset"] + 401] ^= 0x40           # one bit inside a section's payload
+    rejected(flipped, "CRC-32")
+    cache.read_file(str(tmp_path / "bad.bin"), verify=False)   # (the same file opens unverified)
