@@ -307,16 +307,21 @@ def main():
     idx_train = torch.arange(n_train, device=dev)
     torch.cuda.synchronize()
 
+    labels_train = labels[idx_train]
+
     def epoch(dense_loss=False):
         model.train()
         opt.zero_grad(set_to_none=True)
-        out = fwd_model(x, adj)
         if world > 1:
+            out = fwd_model(x, adj)
             loss = fwd_model.nll_loss(out.float(), labels, None if dense_loss else idx_train)
         elif dense_loss:
-            loss = F.nll_loss(out.float(), labels)
+            loss = F.nll_loss(fwd_model(x, adj).float(), labels)
         else:
-            loss = F.nll_loss(out[idx_train].float(), labels[idx_train])
+            # upstream: F.nll_loss(output[idx_train], labels[idx_train]) (train.py:153) — the model is
+            # told which rows the loss reads, so the backward pass runs on the rows that can be
+            # non-zero (pygcn_amd/fused.py); the forward pass is the full one
+            loss = F.nll_loss(fwd_model(x, adj, rows=idx_train).float(), labels_train)
         loss.backward()
         if world > 1:
             fwd_model.allreduce_grads()
@@ -459,7 +464,7 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_note = measured_traffic(args.config, dt) if world == 1 else \
             (None, "single-GPU figure only")
-        syncs = 0 if args.spmm_only else (4 if world == 1 and n >= spmm_mod.MIN_ROWS else None)
+        syncs = 0 if (args.spmm_only or world == 1) else None
         line = {
             "metric": "SpMM GEdge/s + fwd+bwd ms/epoch, 10M-node synthetic CSR, feat_dim=256",
             "value": round(gedges, 4), "unit": "GEdge/s", "n_gpus": world,
@@ -496,18 +501,19 @@ def main():
             "tolerance_note": "parity contract 1e-5 relative is per step (one forward/backward); "
                               "a 200-epoch Adam trajectory is gated at 1e-3 (chained fp32 steps)",
             "host_syncs_per_step": syncs,
-            "host_syncs_note": ("two device->host reads of a non-zero-row count per layer backward "
-                                "(row compaction of the gradient GEMMs, pygcn_amd/spmm.py)")
-            if syncs else None,
+            "host_syncs_note": ("none inside the timed region: the rows every gradient can be "
+                                "non-zero on follow from the graph and idx_train, computed once "
+                                "before the timed region (pygcn_amd/fused.py)") if world == 1 else
+                               "one count exchange per row-sparse gradient exchange (sharded.py)",
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
-            "spmm_bwd_note": ("layer 2: transpose product that skips the all-zero rows of its dense "
-                              "operand (gradients of the idx_train loss: 5 % of the rows non-zero); "
-                              "layer 1 (input needs no gradient): grad_W = (A x X)^T x grad_pre from a "
-                              "forward product restricted to the 16 % of the rows that meet a "
-                              "non-zero row of grad_pre (80 % of the stored entries); `value` and "
-                              "`roofline` are the unrestricted forward product") if world == 1 else
+            "spmm_bwd_note": ("layer 2: transpose product restricted to the operand rows idx_train (5 % "
+                              "of the rows) and to the output rows that have a neighbour in idx_train "
+                              "(16 %); layer 1 (input needs no gradient): grad_W = (A x X)^T x grad_pre "
+                              "from a forward product restricted to those 16 % of the rows (80 % of "
+                              "the stored entries); `value` and `roofline` are the unrestricted "
+                              "forward product; the dense-gradient epoch is reported beside it") if world == 1 else
                              "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),

@@ -1,0 +1,199 @@
+"""The 2-layer GCN training step as ONE autograd node when the loss reads a known set of rows.
+
+Upstream's epoch (reference pygcn/train.py:140-157, kept there as comments) is
+
+    output = model(features, adj)                                   models.py:47-71 (upstream form)
+    loss_train = F.nll_loss(output[idx_train], labels[idx_train])   train.py:153
+    loss_train.backward()                                           train.py:157
+
+so the gradient that enters the model is non-zero on the rows `idx_train` only — and which rows of
+every later gradient CAN be non-zero follows from the graph alone:
+
+    grad_pre2 = d loss / d (Â·h1·W2 + b2)      rows  R  = idx_train
+    grad_sup2 = Âᵀ · grad_pre2                 rows  R2 = vertices that have a neighbour in R
+    grad_W2   = h1ᵀ · grad_sup2,  grad_h1 = grad_sup2 · W2ᵀ,  grad_pre1 = mask(grad_h1)   rows R2
+    grad_W1   = (Â·X)ᵀ · grad_pre1 = (Â·X)[R2]ᵀ · grad_pre1[R2]
+
+`model(features, adj, rows=idx_train)` returns `output[idx_train]` from a node that keeps all of
+this inside: R2 is computed once per (graph, rows) from the CSR structure, every intermediate
+gradient lives in COMPACT form ([|R|, C] and [|R2|, H] tensors), the two sparse products are the
+row-restricted launches of the HIP kernel (operand-row hint + output-row selection,
+`gcn_epilogue.b_row_nonzero / c_row_select`), and nothing of size [N, ·] is zero-filled,
+scattered into, or swept to find its non-zero rows.  Compared with letting the dense
+`grad_output [N, C]` travel through autograd this removes per epoch at config C4: the 10 GB zero
+fill of index_put's backward and its scatter, the NLL kernels over [N, C], two full-height
+backward sweeps and the scatter of grad_h1 — ≈ 11 ms of an 84 ms epoch — and every host
+synchronisation of the backward pass (the row sets are static, their sizes are known on the host).
+Only structurally-zero rows are skipped: the result is the same sum of the same products.
+
+The forward pass is the ordinary one (both products over all rows, fused bias / ReLU / dropout /
+log_softmax epilogues): the full log-probability matrix exists and can be kept (`keep_full=True`)
+for validation on other rows, as upstream's --fastmode does.
+"""
+import weakref
+
+import torch
+
+from .graph import CSRGraph
+from . import spmm as _spmm
+from .spmm import (_dense_forward, _weight_grad, gemm_xw256, log_softmax_fusable, pack_row_flags,
+                   spmm_csr)
+
+
+def _maybe_poisoned(shape, dtype, device):      # (reads the test switch at call time)
+    return _spmm._maybe_poisoned(shape, dtype, device)
+
+
+class RowSets:
+    """What the backward pass needs to know about the loss rows R, computed ONCE per
+    (graph, rows tensor): R sorted and unique, its bitmap / count (operand hint of Âᵀ·grad_pre2),
+    R2 = the columns that occur in rows R of Â (= the rows of Âᵀ·grad_pre2 that can be non-zero)
+    with its bitmap / count (output-row selection of both restricted products)."""
+
+    def __init__(self, graph, rows):
+        dev, n = graph.device, graph.shape[0]
+        rows = rows.to(device=dev, dtype=torch.int64)
+        if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= n):
+            raise RuntimeError("rows: index out of range")
+        self.rows_user = rows
+        self.rows_u, self.inverse = torch.unique(rows, return_inverse=True)      # sorted
+        self.has_duplicates = self.rows_u.numel() != rows.numel()
+        self.n_u = int(self.rows_u.numel())
+        mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        mask[self.rows_u] = True
+        self.hint = pack_row_flags(mask)                                         # (bitmap, count)
+        rp = graph.rowptr.to(torch.int64)
+        starts, lens = rp[self.rows_u], rp[self.rows_u + 1] - rp[self.rows_u]
+        total = int(lens.sum())
+        idx = torch.repeat_interleave(starts - torch.cumsum(lens, 0) + lens, lens) + \
+            torch.arange(total, device=dev)
+        self.rows2 = torch.unique(graph.col[idx].to(torch.int64))                # sorted
+        self.n2 = int(self.rows2.numel())
+        mask2 = torch.zeros(graph.shape[1], dtype=torch.bool, device=dev)
+        mask2[self.rows2] = True
+        self.hint2 = pack_row_flags(mask2)
+
+
+_ROWSETS = weakref.WeakKeyDictionary()    # graph -> {(rows ptr, numel, version): RowSets}
+
+
+def row_sets(graph, rows):
+    per_graph = _ROWSETS.setdefault(graph, {})
+    key = (rows.data_ptr(), rows.numel(), rows._version, rows.dtype)
+    rs = per_graph.get(key)
+    if rs is None:
+        if len(per_graph) >= 4:
+            per_graph.clear()
+        rs = per_graph[key] = (RowSets(graph, rows), rows)     # (keeps `rows` alive: ptr stays unique)
+    return rs[0]
+
+
+def fusable(model_dtype, nclass, graph, x):
+    """Shapes / layouts the one-node path covers; anything else takes the layer-by-layer path."""
+    return (isinstance(graph, CSRGraph) and x.dim() == 2 and x.is_cuda and graph.shape[0] == graph.shape[1]
+            and log_softmax_fusable(nclass, model_dtype))
+
+
+def _rows_honoured(n, width, dtype, count):
+    """The device-side rule of the product (use_row_flags in gcn_spmm.hip, mirrored by
+    spmm._hint_will_be_used) for a freshly allocated [n, width] operand: rows whose hint bit is
+    clear are skipped below 3/4 non-zero rows in the wide kernel, below 1/8 in the narrow one."""
+    v = 16 // torch.empty((), dtype=dtype).element_size()
+    wide = width % v == 0 and width // v > 32
+    return count * 4 < n * 3 if wide else count * 8 < n
+
+
+def _operand_buffer(n, width, dtype, device, rows, values, count):
+    """[n, width] tensor holding `values` at `rows`; the other rows are left UNWRITTEN when the
+    product that reads it is certain to honour the row hint (it then never touches them), and are
+    zero otherwise."""
+    buf = _maybe_poisoned((n, width), dtype, device) if _rows_honoured(n, width, dtype, count) \
+        else torch.zeros((n, width), dtype=dtype, device=device)
+    buf.index_copy_(0, rows, values)
+    return buf
+
+
+class GCN2RowsFunction(torch.autograd.Function):
+    """log_softmax(Â·dropout(relu(Â·X·W1 + b1))·W2 + b2)[rows] — models.py:47-71 (upstream form) —
+    with the whole backward pass of the module docstring.  Outputs: (out_rows, full log-probability
+    matrix or None); the second output is not differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, graph, rows, dropout_p, seed, keep_full):
+        rs = row_sets(graph, rows)
+        ctx.graph, ctx.rs = graph, rs
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        h1 = spmm_csr(graph, _dense_forward(x, w1), bias=b1, relu=True, dropout_p=dropout_p,
+                      seed=seed)
+        logp = spmm_csr(graph, _dense_forward(h1, w2), bias=b2, log_softmax=True)
+        out_rows = logp.index_select(0, rows.to(torch.int64))
+        ctx.save_for_backward(x, w1, w2, h1, out_rows)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.bias_dtypes = (b1.dtype if b1 is not None else None, b2.dtype if b2 is not None else None)
+        if keep_full:
+            ctx.mark_non_differentiable(logp)
+            return out_rows, logp
+        return out_rows, None
+
+    @staticmethod
+    def backward(ctx, grad_rows, _grad_full):
+        x, w1, w2, h1, out_rows = ctx.saved_tensors
+        graph, rs = ctx.graph, ctx.rs
+        need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad[:5]
+        n, dev, dt = graph.shape[0], x.device, h1.dtype
+        graph_t = graph.t()
+        # ---- loss rows: log_softmax backward on [|R|, C]
+        g = grad_rows.float()
+        gp = g - out_rows.float().exp() * g.sum(1, keepdim=True)
+        dst_rows = rs.rows_user                            # where the rows of gp belong in [N, C]
+        if rs.has_duplicates:                              # the same vertex listed twice: add up
+            gp = torch.zeros((rs.n_u, gp.shape[1]), dtype=gp.dtype, device=dev).index_add_(
+                0, rs.inverse, gp)
+            dst_rows = rs.rows_u
+        grad_b2 = gp.sum(0).to(ctx.bias_dtypes[1]) if (ctx.has_bias[1] and need_b2) else None
+        gp = gp.to(dt)
+        grad_w1 = grad_w2 = grad_b1 = grad_x = None
+        if not (need_x or need_w1 or need_b1 or need_w2):
+            return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
+        # ---- layer 2: Âᵀ · grad_pre2 restricted to operand rows R and output rows R2
+        grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
+        grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd", b_hint=rs.hint, c_select=rs.hint2[0],
+                             out=_maybe_poisoned((n, gp.shape[1]), dt, dev))
+        gs2 = grad_sup2.index_select(0, rs.rows2)           # [|R2|, C]
+        del grad_pre2, grad_sup2
+        h1c = h1.index_select(0, rs.rows2)                  # [|R2|, H]
+        if need_w2:
+            grad_w2 = _weight_grad(h1c, gs2)
+        gh1 = gemm_xw256(gs2, w2.t().contiguous())
+        if gh1 is None:
+            gh1 = torch.mm(gs2, w2.t())
+        del gs2
+        # ---- ReLU / dropout mask on the compact rows (out > 0 encodes ReLU and keep)
+        gpre1 = torch.where(h1c > 0, gh1 * ctx.scale if ctx.scale != 1.0 else gh1,
+                            torch.zeros((), dtype=dt, device=dev))
+        del gh1, h1c
+        if ctx.has_bias[0] and need_b1:
+            grad_b1 = gpre1.float().sum(0).to(ctx.bias_dtypes[0])
+        # ---- layer 1
+        if not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
+            if need_w1:
+                # grad_W1 = (Â·X)[R2]ᵀ · grad_pre1[R2]: a forward product restricted to rows R2
+                z = spmm_csr(graph, x, tag="bwd", c_select=rs.hint2[0],
+                             out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
+                grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
+        elif need_x or need_w1:
+            grad_pre1 = _operand_buffer(n, gpre1.shape[1], dt, dev, rs.rows2, gpre1, rs.n2)
+            grad_sup1 = spmm_csr(graph_t, grad_pre1, tag="bwd", b_hint=rs.hint2)
+            if need_w1:
+                grad_w1 = _weight_grad(x, grad_sup1)
+            if need_x:
+                grad_x = gemm_xw256(grad_sup1, w1.t().contiguous())
+                if grad_x is None:
+                    grad_x = torch.mm(grad_sup1, w1.t())
+        return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
+
+
+def gcn2_rows(x, gc1, gc2, graph, rows, dropout_p, seed, keep_full=False):
+    """(output[rows], full output or None) of the 2-layer model through the one-node path."""
+    return GCN2RowsFunction.apply(x, gc1.weight, gc1.bias, gc2.weight, gc2.bias, graph, rows,
+                                  float(dropout_p), seed, bool(keep_full))

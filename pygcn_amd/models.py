@@ -23,12 +23,46 @@ class GCN(nn.Module):
         self.gc2 = GraphConvolution(nhid, nclass)
         self.dropout = dropout
 
-    def forward(self, x, adj):
+    def forward(self, x, adj, rows=None, keep_full=False):
+        """`model(x, adj)`: the reference call — log-probabilities of every vertex.
+
+        `model(x, adj, rows=idx)` (extension): the same forward pass, returning `output[idx]` —
+        what upstream's epoch feeds to the loss, `F.nll_loss(output[idx_train], labels[idx_train])`
+        (pygcn/train.py:153).  Telling the model which rows the loss reads lets the whole backward
+        pass run on the rows that can be non-zero (pygcn_amd/fused.py): same gradients, no
+        [N, ·]-sized zero fills, scatters or sweeps, no host synchronisation.  With
+        `keep_full=True` the result is `(output[idx], output.detach())` — the full matrix for
+        validation on other rows, as upstream's --fastmode uses it."""
+        if rows is not None:
+            return self._forward_rows(x, adj, rows, keep_full)
         # F.dropout(F.relu(gc1(x, adj)), p, training) with ReLU and dropout fused into the SpMM store
         x = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
         # F.log_softmax(gc2(x, adj), dim=1) — in the SpMM's store when a row fits one wavefront
         # (dim=1 for the reference's [N, C]; the last dim if batched)
         return self.gc2(x, adj, log_softmax=True)
+
+    def _forward_rows(self, x, adj, rows, keep_full):
+        import torch
+        if __package__:
+            from pygcn_amd import fused
+            from pygcn_amd.graph import CSRGraph, as_graph
+            from pygcn_amd.spmm import dropout_seed_for
+        else:
+            import pygcn_amd.fused as fused
+            from pygcn_amd.graph import CSRGraph, as_graph
+            from pygcn_amd.spmm import dropout_seed_for
+        graph = adj
+        if isinstance(adj, torch.Tensor) and adj.layout in (torch.sparse_coo, torch.sparse_csr) \
+                and adj.is_cuda:
+            graph = as_graph(adj)
+        if isinstance(graph, CSRGraph) and fused.fusable(self.gc2.weight.dtype, self.gc2.out_features,
+                                                         graph, x):
+            p = self.dropout if self.training else 0.0
+            seed = dropout_seed_for(x) if p > 0.0 else 0
+            out, full = fused.gcn2_rows(x, self.gc1, self.gc2, graph, rows, p, seed, keep_full)
+            return (out, full) if keep_full else out
+        full = self.forward(x, adj)          # layer-by-layer path (sharded / dense adjacency / odd shapes)
+        return (full[rows], full.detach()) if keep_full else full[rows]
 
 
 class GCNStack(nn.Module):

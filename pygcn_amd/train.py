@@ -72,8 +72,12 @@ class Run:
         started = time.time()
         self.model.train()
         self.opt.zero_grad()
-        log_probs = self.model(self.features, self.adj)
-        loss, acc = self.score(log_probs, "train")
+        # upstream: output = model(features, adj); loss_train = F.nll_loss(output[idx_train], ...)
+        # (train.py:150-153).  Same forward pass; the model is told which rows the loss reads so
+        # that the backward pass stays on the rows that can be non-zero (pygcn_amd/fused.py)
+        rows = self.split["train"]
+        train_rows, log_probs = self.model(self.features, self.adj, rows=rows, keep_full=True)
+        loss, acc = nll_loss(train_rows, self.labels[rows]), accuracy(train_rows, self.labels[rows])
         loss.backward()
         self.opt.step()
         if not self.fastmode:          # upstream re-evaluates with dropout off for validation

@@ -1,0 +1,188 @@
+"""`model(x, adj, rows=idx)` — the 2-layer training step as one autograd node (pygcn_amd/fused.py)
+— against the oracle's forward / loss / backward (reference semantics: pygcn/train.py:153-157 with
+the upstream model of models.py:23,48,50,68).  Tensors whose rows are left unwritten on purpose
+are pre-filled with NaN in these tests, so reading a row that must not be read poisons the result."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from conftest import assert_normwise, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def poison():
+    from pygcn_amd import spmm as S
+    S._poison_unwritten = True
+    yield
+    S._poison_unwritten = False
+
+
+def _check(model, x, adj_graph, a, labels, idx, oracle, tol_w=2e-5, need_x=False):
+    dev = x.device
+    idx_t = torch.from_numpy(np.asarray(idx)).to(dev)
+    model.train()
+    model.zero_grad()
+    out_rows, full = model(x, adj_graph, rows=idx_t, keep_full=True)
+    loss = torch.nn.functional.nll_loss(out_rows, torch.from_numpy(labels).to(dev)[idx_t])
+    loss.backward()
+    p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref_loss, fw, grads, extra = oracle.gcn2_loss_backward(x.detach().cpu().numpy(), a, p, labels,
+                                                           np.asarray(idx), need_grad_x=need_x)
+    assert not full.requires_grad
+    assert_normwise(full.cpu(), fw["logp"], TOL, "full log-probabilities")
+    assert_normwise(out_rows.detach().cpu(), fw["logp"][np.asarray(idx)], TOL, "selected rows")
+    assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss)
+    for k, v in grads.items():
+        mod, name = k.split(".")
+        got = getattr(getattr(model, mod), name).grad
+        assert got is not None and torch.isfinite(got).all(), k
+        assert_normwise(got.cpu(), v, tol_w, k + ".grad")
+    if need_x:
+        assert_normwise(x.grad.cpu(), extra["grad_x"], TOL, "grad_x")
+    # and it is the same function as the plain call + indexing
+    model.zero_grad()
+    plain = model(x.detach(), adj_graph)
+    loss2 = torch.nn.functional.nll_loss(plain[idx_t], torch.from_numpy(labels).to(dev)[idx_t])
+    assert abs(loss2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+
+
+def test_cora_step_through_the_one_node_path(oracle, dev, poison):
+    """Config C2 shapes (1433 -> 16 -> 7): wide first layer, so layer 1 takes the transpose-product
+    branch; adjacency handed over as the torch sparse COO tensor the reference builds."""
+    from pygcn_amd import GCN
+    from pygcn_amd.utils import load_data
+    adj, _, _, idx_train, _, _ = load_data()
+    g = np.load(gin.__file__.replace("inputs.py", "cora_graph.npz"))
+    a = oracle.cora_adjacency(g["edges"], int(g["n"]))
+    x = torch.from_numpy(gin.cora_features()).to(dev)
+    torch.manual_seed(42)
+    model = GCN(1433, 16, 7, dropout=0.0).to(dev)
+    _check(model, x, adj.to(dev), a, gin.cora_labels(), idx_train.numpy(), oracle)
+    g2 = load_golden("g2_cora_step.npz")
+    assert_normwise(model.gc1.weight.grad.cpu(), g2["grad_gc1_weight"], 2e-5, "G2 grad_gc1_weight") \
+        if "grad_gc1_weight" in g2.files else None
+
+
+@pytest.mark.parametrize("fin,hid,ncls,share", [(256, 256, 256, 0.05), (48, 64, 16, 0.3), (256, 256, 64, 0.9),
+                                                (700, 32, 8, 0.02)])
+def test_rmat_step_matches_oracle(oracle, dev, poison, fin, hid, ncls, share):
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.utils import rmat_graph
+    n = 30000
+    rowptr, col, val = rmat_graph(n, 300000, seed=21, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    rng = np.random.default_rng(fin + ncls)
+    x = torch.from_numpy(gin.dense((n, fin), 5)).to(dev)
+    labels = rng.integers(0, ncls, n)
+    idx = rng.permutation(n)[: int(n * share)]            # unsorted on purpose
+    torch.manual_seed(1)
+    model = GCN(fin, hid, ncls, dropout=0.0).to(dev)
+    _check(model, x, g, a, labels, idx, oracle)
+
+
+def test_duplicate_rows_input_gradient_and_dropout(oracle, dev, poison):
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd import spmm as S
+    from pygcn_amd.utils import rmat_graph
+    n, F = 20000, 64
+    rowptr, col, val = rmat_graph(n, 150000, seed=22, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, F, n)
+    idx = np.concatenate([rng.integers(0, n, 900), [7, 7, 7, n - 1]])      # duplicates
+    torch.manual_seed(2)
+    model = GCN(F, F, F, dropout=0.0).to(dev)
+    x = torch.from_numpy(gin.dense((n, F), 6)).to(dev).requires_grad_(True)    # input gradient too
+    _check(model, x, g, a, labels, idx, oracle, need_x=True)
+    # training-mode dropout: the one-node path and the layer-by-layer path draw the same mask from
+    # the same generator state, so their gradients agree (layer path = the tested reference here)
+    model.dropout = 0.4
+    idx_t = torch.from_numpy(idx).to(dev)
+    y = torch.from_numpy(labels).to(dev)[idx_t]
+    grads = []
+    for fused in (True, False):
+        model.zero_grad()
+        torch.manual_seed(11)
+        out = model(x.detach(), g, rows=idx_t) if fused else model(x.detach(), g)[idx_t]
+        torch.nn.functional.nll_loss(out, y).backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for p, q in zip(*grads):
+        assert (p - q).abs().max().item() <= 2e-5 * q.abs().max().item()
+
+
+def test_bf16_one_node_path(oracle, dev):
+    """C5 numerics (bf16 storage) through the one-node path, against the oracle on the bf16-rounded
+    parameters / inputs (same gates as test_bf16_model_end_to_end)."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.utils import rmat_graph
+    n, F = 20000, 128
+    rowptr, col, val = rmat_graph(n, 200000, seed=3, device="cpu")
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    x16 = torch.from_numpy(gin.dense((n, F), 1)).to(torch.bfloat16)
+    y = np.random.default_rng(2).integers(0, F, n)
+    idx = np.arange(n // 10)
+    torch.manual_seed(5)
+    m16 = GCN(F, F, F, dropout=0.0).to(torch.bfloat16).to(dev)
+    idx_t = torch.from_numpy(idx).to(dev)
+    out = m16(x16.to(dev), g, rows=idx_t)
+    assert out.dtype == torch.bfloat16 and out.shape == (len(idx), F)
+    loss = torch.nn.functional.nll_loss(out.float(), torch.from_numpy(y).to(dev)[idx_t])
+    loss.backward()
+    p = {k: v.detach().float().cpu().numpy() for k, v in m16.state_dict().items()}
+    ref_loss, fw, grads, _ = oracle.gcn2_loss_backward(x16.float().numpy(), a, p, y, idx)
+    assert_normwise(out.float().detach().cpu(), fw["logp"][idx], 2.0 ** -6, "logp rows")
+    assert abs(loss.item() - ref_loss) <= 2.0 ** -6 * abs(ref_loss)
+    for k, v in grads.items():
+        mod, name = k.split(".")
+        assert_normwise(getattr(getattr(m16, mod), name).grad.float().cpu(), v, 2.0 ** -4, k + ".grad")
+
+
+def test_backward_pass_has_no_host_synchronisation(dev, monkeypatch):
+    """After the row sets of (graph, rows) exist, a training step through the one-node path reads
+    nothing back to the host — so it can be captured into a hipGraph."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.utils import rmat_graph
+    n, F = 200000, 256                      # >= MIN_ROWS: the layer-by-layer path would synchronise
+    rowptr, col, val = rmat_graph(n, 2000000, seed=4, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    g.plan(), g.t().plan()
+    x = torch.randn(n, F, device=dev)
+    y = torch.randint(0, F, (n,), device=dev)
+    idx = torch.arange(n // 20, device=dev)
+    y_idx = y[idx]
+    model = GCN(F, F, F, dropout=0.5).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.nll_loss(model(x, g, rows=idx), y_idx)
+        loss.backward()
+        opt.step()
+        return loss
+    step()                                   # builds the row sets (one-off host reads)
+    torch.cuda.synchronize()
+    reads = []
+    for name in ("item", "tolist", "cpu"):
+        real = getattr(torch.Tensor, name)
+        monkeypatch.setattr(torch.Tensor, name,
+                            (lambda r, nm: lambda t, *a, **k: (reads.append(nm) if t.is_cuda else None,
+                                                               r(t, *a, **k))[1])(real, name))
+    real_nonzero = torch.nonzero
+    monkeypatch.setattr(torch, "nonzero", lambda *a, **k: (reads.append("nonzero"), real_nonzero(*a, **k))[1])
+    l1 = step()
+    monkeypatch.undo()
+    assert reads == [], reads
+    assert torch.isfinite(l1).item()
