@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 13
+#define GCN_ABI_VERSION 14
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -314,6 +314,21 @@ int gcn_row_normalize_device(const void *rowptr, int rowptr_is64, float *val, in
 size_t gcn_gemm_xw256_workspace_bytes(void);
 int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y, int64_t ldy,
                        int64_t M, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The same product by a cheaper decomposition: both operands are scaled by exact powers of two and
+ * split into TWO fp16 parts, three fp16 MFMAs per product (half the matrix work of the 3 x bf16
+ * form; error <= ~2^-21 relative per product, normwise ~1e-6 against an fp64 product).  fp16 has
+ * little range, so the caller supplies x_absmax_bound: a DEVICE float holding any upper bound of
+ * max|X| (the tighter, the more of fp16's 2^17 usable dynamic range is kept below the maximum;
+ * elements further below it lose relative — not absolute — precision).  y_absmax: optional DEVICE
+ * float, zeroed by the caller, receives max|Y| (atomic max) — the bound a following layer needs.
+ * Workspace >= gcn_gemm_xw256_h2_workspace_bytes().  `torch.mm(input, weight)`, pygcn/layers.py:33.
+ */
+size_t gcn_gemm_xw256_h2_workspace_bytes(void);
+int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y,
+                          int64_t ldy, int64_t M, const float *x_absmax_bound, float *y_absmax,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

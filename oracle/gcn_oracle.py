@@ -231,7 +231,7 @@ def gcn2_loss_backward(x, adj, p, labels, idx, need_grad_x=False):
     n_tr = len(idx)
     loss = float(-logp[idx, labels[idx]].astype(np.float64).mean())
     grad_logp = np.zeros_like(logp)
-    grad_logp[idx, labels[idx]] = -1.0 / n_tr
+    np.add.at(grad_logp, (idx, labels[idx]), np.float32(-1.0 / n_tr))   # (a vertex listed twice counts twice)
     # log_softmax backward: g - softmax * sum(g)
     grad_h2 = (grad_logp - np.exp(logp) * grad_logp.sum(1, keepdims=True)).astype(np.float32)
     ga1, gw2, gb2, _ = gc_backward(fw["a1"], p["gc2.weight"], "gc2.bias" in p, adj, grad_h2)

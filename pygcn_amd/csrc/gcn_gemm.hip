@@ -257,6 +257,228 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Second scheme: TWO fp16 parts after an exact power-of-two scaling, three MFMAs per product.
+//
+// fp16 carries 11 significant bits, so x = h + m with h = fp16(x), m = fp16(x - h) represents x
+// to 2^-22 relative, and  x·w ≈ h·h' + h·m' + m·h'  drops only the m·m' term (<= 2^-22): half the
+// MFMA work of the 3 x bf16 scheme above at an error that stays well inside the path's 1e-5
+// contract (measured against an fp64 product: tests/test_gemm_gpu.py).  What fp16 lacks is RANGE
+// (max 65504, normals down to 2^-14), so both operands are first multiplied by a power of two
+// (exact in fp32): W by 2^(14 - floor(log2 max|W|)), computed by the prep kernel; X by
+// 2^(14 - floor(log2 B)) where B is any upper bound of max|X| the caller supplies in DEVICE memory
+// — the layer knows one for free (the previous GEMM's output maximum times the adjacency's
+// infinity norm, see pygcn_amd/spmm.py) — and the accumulators are scaled back on the way out.
+// Elements more than 2^17 below the tensor's maximum lose RELATIVE precision (their m part goes
+// subnormal): the absolute error per element is bounded by 2^-38 · max|X|; inputs with a wider
+// dynamic range that matters should use the 3 x bf16 entry point.  Optionally the kernel reports
+// max|Y| (one atomic max per wave) — the next layer's bound.
+constexpr int kH2ChunkBytes = 2 * 8 * kFragBytes;          // 2 splits x 8 column blocks = 16 KiB
+constexpr int kH2StageBytes = kStage * kH2ChunkBytes;
+constexpr int kH2WLoads = kH2StageBytes / 16 / kThreads;
+static_assert(kH2StageBytes % (16 * kThreads) == 0, "W stage must divide over the workgroup");
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// exponent e with 2^e <= v < 2^(e+1) for finite v > 0 (0 for zero / non-finite: no scaling)
+__device__ __forceinline__ int floor_log2f(float v)
+{
+    const uint32_t b = __float_as_uint(v) & 0x7fffffffu;
+    const int e = (int)(b >> 23);
+    if (b == 0 || e == 255) return 0;
+    if (e == 0) return -126 - __clz(b << 9) - 1;          // fp32 subnormal
+    return e - 127;
+}
+
+__device__ __forceinline__ float pow2f(int e)              // 2^e for -126 <= e <= 127
+{
+    return __uint_as_float((uint32_t)(e + 127) << 23);
+}
+
+// header of the workspace the prep kernel writes in front of the W image
+struct H2Header {
+    int w_exp;        // W was multiplied by 2^w_exp
+    int pad[3];
+};
+constexpr int kH2HeaderBytes = 256;
+
+// one workgroup: max|W|, scale, split into fp16 (h, m), fragment-ordered like the bf16 image
+__global__ __launch_bounds__(1024) void split_w_h2_kernel(const float *__restrict__ W, int64_t ldw,
+                                                          unsigned char *__restrict__ ws)
+{
+    __shared__ float red[16];
+    __shared__ int s_exp;
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (int i = tid; i < kK * kN; i += 1024) mx = fmaxf(mx, fabsf(W[(int64_t)(i >> 8) * ldw + (i & 255)]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i]);
+        int e = 14 - floor_log2f(m);
+        e = e > 126 ? 126 : (e < -126 ? -126 : e);
+        if (!(m > 0.f) || !(m <= 3.4028235e38f)) e = 0;
+        s_exp = e;
+        ((H2Header *)ws)->w_exp = e;
+    }
+    __syncthreads();
+    const float sc = pow2f(s_exp);
+    uint16_t *img = (uint16_t *)(ws + kH2HeaderBytes);
+    for (int idx = tid; idx < kChunks * 8 * 64; idx += 1024) {          // one (chunk, cb, lane)
+        const int lane = idx & 63, cb = (idx >> 6) & 7, chunk = idx >> 9;
+        const int n = 32 * cb + (lane & 31);
+        const int k0 = kChunk * chunk + 8 * (lane >> 5);
+        uint16_t *base = img + (size_t)chunk * (kH2ChunkBytes / 2);
+        uint16_t *dh = base + ((0 * 8 + cb) * 64 + lane) * 8;
+        uint16_t *dm = base + ((1 * 8 + cb) * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = W[(int64_t)(k0 + j) * ldw + n] * sc;
+            const _Float16 h = (_Float16)x;
+            const _Float16 m = (_Float16)(x - (float)h);
+            dh[j] = __builtin_bit_cast(uint16_t, h);
+            dm[j] = __builtin_bit_cast(uint16_t, m);
+        }
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a),
+                                                  __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
+    const float *__restrict__ X, int64_t ldx, const unsigned char *__restrict__ ws,
+    const float *__restrict__ x_bound, float *__restrict__ Y, int64_t ldy, int64_t M,
+    uint32_t *__restrict__ y_absmax)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = (int64_t)blockIdx.x * kTileRows + 32 * wave + (lane & 31);
+    const bool row_ok = row < M;
+    const float *xrow = X + (row_ok ? row : 0) * ldx + 8 * (lane >> 5);
+    const unsigned char *wimg = ws + kH2HeaderBytes;
+
+    // scales (wave-uniform scalars)
+    int x_exp = 14 - floor_log2f(*x_bound);
+    x_exp = x_exp > 126 ? 126 : (x_exp < -126 ? -126 : x_exp);
+    {
+        const float b = *x_bound;
+        if (!(b > 0.f) || !(b <= 3.4028235e38f)) x_exp = 0;
+    }
+    const float xs = pow2f(x_exp);
+    const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
+    const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);   // exact steps
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+    u32x4 wreg[kH2WLoads];
+    auto w_load = [&](int st) {
+        const u32x4 *src = (const u32x4 *)(wimg + (size_t)st * kH2StageBytes);
+#pragma unroll
+        for (int i = 0; i < kH2WLoads; ++i) wreg[i] = src[i * kThreads + tid];
+    };
+    auto w_store = [&](int b) {
+        u32x4 *dst = (u32x4 *)(lds + b * kH2StageBytes);
+#pragma unroll
+        for (int i = 0; i < kH2WLoads; ++i) dst[i * kThreads + tid] = wreg[i];
+    };
+    f32x4 ar[3][2];
+    auto a_fetch = [&](int c, f32x4 &lo, f32x4 &hi) {
+        const f32x4 *p = (const f32x4 *)(xrow + c * kChunk);
+        lo = p[0];
+        hi = p[1];
+    };
+    u32x4 Ah, Am;
+    auto split_frag = [&](const f32x4 &lo, const f32x4 &hi) {
+        const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t h[4], m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x0 = row_ok ? av[2 * j] * xs : 0.f, x1 = row_ok ? av[2 * j + 1] * xs : 0.f;
+            f32x2 v = {x0, x1};
+            const h16x2 hh = __builtin_convertvector(v, h16x2);
+            const f32x2 hb = __builtin_convertvector(hh, f32x2);
+            f32x2 r = {x0 - hb.x, x1 - hb.y};
+            const h16x2 mm = __builtin_convertvector(r, h16x2);
+            h[j] = __builtin_bit_cast(uint32_t, hh);
+            m[j] = __builtin_bit_cast(uint32_t, mm);
+        }
+        Ah = u32x4{h[0], h[1], h[2], h[3]};
+        Am = u32x4{m[0], m[1], m[2], m[3]};
+    };
+
+    w_load(0);
+    a_fetch(0, ar[0][0], ar[0][1]);
+    a_fetch(1, ar[1][0], ar[1][1]);
+    w_store(0);
+    split_frag(ar[0][0], ar[0][1]);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        const int st = c / kStage;
+        if (c % kStage == 0) {
+            __syncthreads();
+            if ((st + 1) * kStage < kChunks) w_load(st + 1);
+        }
+        if (c + 2 < kChunks) a_fetch(c + 2, ar[(c + 2) % 3][0], ar[(c + 2) % 3][1]);
+        const u32x4 Xh = Ah, Xm = Am;
+        const unsigned char *buf = lds + (st & 1) * kH2StageBytes + (c % kStage) * kH2ChunkBytes;
+        u32x4 Bf[2][2];
+        auto b_read = [&](int nb, u32x4 (&dst)[2]) {
+            dst[0] = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
+            dst[1] = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
+        };
+        b_read(0, Bf[0]);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
+            const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
+            f32x16 t = acc[nb];
+            __builtin_amdgcn_s_setprio(1);
+            t = mfma_h(Bm, Xh, t);       // smaller terms first
+            t = mfma_h(Bh, Xm, t);
+            t = mfma_h(Bh, Xh, t);
+            __builtin_amdgcn_s_setprio(0);
+            acc[nb] = t;
+        }
+        if (c % kStage == kStage - 1 && c + 1 < kChunks) w_store((st + 1) & 1);
+        if (c + 1 < kChunks) {
+            split_frag(ar[(c + 1) % 3][0], ar[(c + 1) % 3][1]);
+            asm volatile("" : "+v"(Ah), "+v"(Am));
+        }
+    }
+
+    float vmax = 0.f;
+    if (row_ok) {
+        float *yrow = Y + row * ldy + 4 * (lane >> 5);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
+                           acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
+                *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+        }
+    }
+    if (y_absmax != nullptr) {                 // |y| >= 0: float order == unsigned order of the bits
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0 && vmax > 0.f) atomicMax(y_absmax, __float_as_uint(vmax));
+    }
+}
+
 }   // namespace
 
 extern "C" {
@@ -284,6 +506,36 @@ int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw,
                        (const uint16_t *)workspace, Y, ldy, M);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32 launch");
+    return 0;
+}
+
+size_t gcn_gemm_xw256_h2_workspace_bytes(void)
+{
+    return (size_t)kH2HeaderBytes + (size_t)kChunks * kH2ChunkBytes;
+}
+
+int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y,
+                          int64_t ldy, int64_t M, const float *x_absmax_bound, float *y_absmax,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
+    if (M == 0) return 0;
+    if (X == nullptr || W == nullptr || Y == nullptr || workspace == nullptr || x_absmax_bound == nullptr)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: NULL pointer");
+    if (workspace_bytes < gcn_gemm_xw256_h2_workspace_bytes())
+        return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw256_f32_h2: workspace too small");
+    if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 4) != 0 ||
+        (ldy % 4) != 0 || (((uintptr_t)x_absmax_bound) | ((uintptr_t)y_absmax)) % 4 != 0)
+        return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32_h2: X / Y rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
+    const int64_t tiles = (M + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
+                       (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                       (uint32_t *)y_absmax);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
     return 0;
 }
 

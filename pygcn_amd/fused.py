@@ -123,9 +123,20 @@ class GCN2RowsFunction(torch.autograd.Function):
         rs = row_sets(graph, rows)
         ctx.graph, ctx.rs = graph, rs
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
-        h1 = spmm_csr(graph, _dense_forward(x, w1), bias=b1, relu=True, dropout_p=dropout_p,
-                      seed=seed)
-        logp = spmm_csr(graph, _dense_forward(h1, w2), bias=b2, log_softmax=True)
+        # bounds of max|operand| for the scaled fp16 GEMM, without a pass over the data:
+        # X is constant (cached), and |relu/dropout(Â·S + b)| <= (‖Â‖∞·max|S| + max|b|) / (1 - p)
+        bounded = x.dtype == torch.float32
+        s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
+        sup1 = _dense_forward(x, w1, _spmm.absmax_cached(x) if bounded else None, s_max)
+        h1 = spmm_csr(graph, sup1, bias=b1, relu=True, dropout_p=dropout_p, seed=seed)
+        del sup1
+        h_bound = None
+        if bounded:
+            h_bound = graph.inf_norm() * s_max
+            if b1 is not None:
+                h_bound = h_bound + b1.detach().abs().max().float()
+            h_bound = h_bound * (1.0001 * ctx.scale)
+        logp = spmm_csr(graph, _dense_forward(h1, w2, h_bound), bias=b2, log_softmax=True)
         out_rows = logp.index_select(0, rows.to(torch.int64))
         ctx.save_for_backward(x, w1, w2, h1, out_rows)
         ctx.has_bias = (b1 is not None, b2 is not None)
@@ -164,7 +175,9 @@ class GCN2RowsFunction(torch.autograd.Function):
         h1c = h1.index_select(0, rs.rows2)                  # [|R2|, H]
         if need_w2:
             grad_w2 = _weight_grad(h1c, gs2)
-        gh1 = gemm_xw256(gs2, w2.t().contiguous())
+        # |Âᵀ·grad_pre2| <= ‖Âᵀ‖∞ · max|grad_pre2|  (max over the small [|R|, C] tensor)
+        gs_bound = graph_t.inf_norm() * gp.abs().max().float() * 1.0001 if dt == torch.float32 else None
+        gh1 = gemm_xw256(gs2, w2.t().contiguous(), gs_bound)
         if gh1 is None:
             gh1 = torch.mm(gs2, w2.t())
         del gs2

@@ -95,6 +95,7 @@ class CSRGraph:
         self._keep = None
         self._t = None
         self._t_val_version = None
+        self._inf_norm = None
         _BY_ARRAYS[_arrays_key(self.rowptr, self.col, self.val, self.shape)] = self
 
     # ------------------------------------------------------------------ constructors
@@ -321,6 +322,17 @@ class CSRGraph:
         _native.check(rc, "gcn_row_normalize_device")
         self._t = None
         return self
+
+    def inf_norm(self):
+        """‖A‖∞ = the largest absolute row sum, as a DEVICE float tensor [1] (computed once): with
+        it, max|A·B| <= ‖A‖∞ · max|B| bounds a product's output without a pass over it."""
+        if self._inf_norm is None or self._inf_norm[0] != self.val._version:
+            row = self.coo()[0]
+            sums = torch.zeros(self.shape[0], dtype=torch.float32, device=self.device).index_add_(
+                0, row, self.val.abs())
+            top = sums.max() if sums.numel() else sums.sum()
+            self._inf_norm = (self.val._version, (top * 1.00001).reshape(1))
+        return self._inf_norm[1]
 
     # ------------------------------------------------------------------ binary cache file
     _PLAN_KEYS = ("items", "chunk_row", "chunk_e0", "long_row", "long_chunk0")

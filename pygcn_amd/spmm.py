@@ -336,29 +336,78 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
-def gemm_xw256(X, W):
-    """X[M,256] · W[256,256] through the hand-written split-bf16 MFMA kernel
-    (C-ABI gcn_gemm_xw256_f32; fp32 in/out, fp32-level accuracy).  None if the operands do not fit
-    the kernel's fixed shape / alignment (the caller then uses torch.mm — hipBLASLt)."""
+def gemm_xw256(X, W, x_bound=None, y_absmax=None):
+    """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
+    accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
+    then uses torch.mm — hipBLASLt).
+
+    Without `x_bound`: C-ABI gcn_gemm_xw256_f32 — operands split into three bf16 parts, six MFMAs
+    per product; no assumption about the data.
+    With `x_bound` (DEVICE float tensor [1], any upper bound of max|X|): C-ABI
+    gcn_gemm_xw256_f32_h2 — power-of-two scaling + two fp16 parts, three MFMAs per product (half
+    the matrix work).  `y_absmax` (DEVICE float tensor [1], zeroed by the caller) then receives
+    max|Y|, from which the caller derives the next layer's bound without a pass over the data."""
     if (X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda or X.dim() != 2
             or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
     Y = torch.empty((X.shape[0], 256), dtype=torch.float32, device=X.device)
-    ws_bytes = L.gcn_gemm_xw256_workspace_bytes()
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     with torch.cuda.device(X.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        if x_bound is not None and _gemm_scheme == "h2":
+            if x_bound.dtype != torch.float32 or x_bound.numel() != 1 or x_bound.device != X.device:
+                raise RuntimeError("gemm_xw256: x_bound must be one float32 on the operand's device")
+            ws_bytes = L.gcn_gemm_xw256_h2_workspace_bytes()
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+            rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0),
+                                         Y.data_ptr(), Y.stride(0), X.shape[0], x_bound.data_ptr(),
+                                         y_absmax.data_ptr() if y_absmax is not None else None,
+                                         ws.data_ptr(), ws_bytes, stream)
+            _native.check(rc, "gcn_gemm_xw256_f32_h2")
+            return Y
+        ws_bytes = L.gcn_gemm_xw256_workspace_bytes()
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
         rc = L.gcn_gemm_xw256_f32(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), Y.data_ptr(),
-                                  Y.stride(0), X.shape[0], ws.data_ptr(), ws_bytes,
-                                  torch.cuda.current_stream().cuda_stream)
+                                  Y.stride(0), X.shape[0], ws.data_ptr(), ws_bytes, stream)
     _native.check(rc, "gcn_gemm_xw256_f32")
+    if y_absmax is not None:
+        y_absmax.copy_(Y.abs().max())
     return Y
 
 
-def _dense_forward(input, weight):
-    out = gemm_xw256(input, weight)
-    return out if out is not None else torch.mm(input, weight)
+_gemm_scheme = "h2"
+
+
+def set_gemm_scheme(name):
+    """"h2": use the scaled two-part fp16 kernel wherever a bound of max|X| is known (default);
+    "bf16x3": always the three-part bf16 kernel (no assumption about the data's dynamic range)."""
+    global _gemm_scheme
+    if name not in ("h2", "bf16x3"):
+        raise RuntimeError("gemm scheme must be 'h2' or 'bf16x3'")
+    _gemm_scheme = name
+
+
+_absmax_cache = {}
+
+
+def absmax_cached(t):
+    """max|t| as a DEVICE float tensor [1], computed once per (storage, version): for operands that
+    stay constant across steps (the feature matrix)."""
+    key = (t.data_ptr(), t.numel(), t._version)
+    hit = _absmax_cache.get(t.device.index)
+    if hit is None or hit[0] != key:
+        hit = _absmax_cache[t.device.index] = (key, t.detach().abs().max().float().reshape(1))
+    return hit[1]
+
+
+def _dense_forward(input, weight, x_bound=None, y_absmax=None):
+    out = gemm_xw256(input, weight, x_bound, y_absmax)
+    if out is None:
+        out = torch.mm(input, weight)
+        if y_absmax is not None:
+            y_absmax.copy_(out.detach().abs().max())
+    return out
 
 
 K_SPLIT = 128          # slabs of the weight-gradient reduction
