@@ -341,18 +341,25 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None):
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
 
-    Without `x_bound`: C-ABI gcn_gemm_xw256_f32 — operands split into three bf16 parts, six MFMAs
-    per product; no assumption about the data.
-    With `x_bound` (DEVICE float tensor [1], any upper bound of max|X|): C-ABI
-    gcn_gemm_xw256_f32_h2 — power-of-two scaling + two fp16 parts, three MFMAs per product (half
-    the matrix work).  `y_absmax` (DEVICE float tensor [1], zeroed by the caller) then receives
-    max|Y|, from which the caller derives the next layer's bound without a pass over the data."""
+    Default scheme "h2": C-ABI gcn_gemm_xw256_f32_h2 — power-of-two scaling + two fp16 parts,
+    three MFMAs per product.  `x_bound` (DEVICE float tensor [1]) is any upper bound of max|X|; if
+    the caller has none, max|X| is computed here by one reduction pass.  `y_absmax` (DEVICE float
+    tensor [1], zeroed by the caller) receives max|Y|, from which a layer derives the next bound
+    without a pass over the data.
+    Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
+    product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
+    underflow — tests/test_gemm_gpu.py)."""
     if (X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda or X.dim() != 2
             or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
     Y = torch.empty((X.shape[0], 256), dtype=torch.float32, device=X.device)
+    if x_bound is None and _gemm_scheme == "h2":
+        # no bound known: one reduction pass over X (1.4 ms at M = 10^7) and the 5.4 ms kernel
+        # still beat the 7.5 ms three-part kernel — and keep full accuracy for tiny operands,
+        # where the third bf16 part would fall into the denormals
+        x_bound = torch.linalg.vector_norm(X.detach(), ord=float("inf")).reshape(1)
     with torch.cuda.device(X.device):
         stream = torch.cuda.current_stream().cuda_stream
         if x_bound is not None and _gemm_scheme == "h2":

@@ -19,9 +19,14 @@ def dev():
 
 def _run(scheme, X, W, bound=None):
     """Y through one of the two kernels; for "h2" the bound defaults to the exact max|X|."""
+    from pygcn_amd import spmm as S
     from pygcn_amd.spmm import gemm_xw256
     if scheme == "bf16x3":
-        return gemm_xw256(X, W)
+        S.set_gemm_scheme("bf16x3")
+        try:
+            return gemm_xw256(X, W)
+        finally:
+            S.set_gemm_scheme("h2")
     finite = torch.where(torch.isfinite(X), X.abs(), torch.zeros_like(X))
     b = (finite.max() if bound is None else torch.as_tensor(bound, device=X.device)).float().reshape(1)
     return gemm_xw256(X, W, x_bound=b)
@@ -79,13 +84,21 @@ def test_gemm_precision_at_the_edges_of_fp32(dev, scheme):
     check(base * 1e37 / 16, W * 0.01, "|x| ~ 1e36..1e37")
     # whole operand deep below the bf16 / fp16 normal range (fp32 normal numbers)
     check(base * 1e-30, W, "|x| ~ 1e-30")
-    check(base * 1e-37, W * 1e3, "|x| ~ 1e-37 (next to the fp32 denormals)")
-    # fp32 denormal inputs (|x| < 1.18e-38): exact scaling keeps their leading bits
-    den = base * 1e-39
-    assert bool((den.abs() < 1.2e-38).all()) and bool((den != 0).any())
-    Y = _run(scheme, den, W * 1e6)
-    ref = den.double() @ (W * 1e6).double()
-    assert float((Y.double() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())   # 2^-10: few bits exist
+    if scheme == "h2":
+        check(base * 1e-37, W * 1e3, "|x| ~ 1e-37 (next to the fp32 denormals)")
+        # fp32 denormal inputs (|x| < 1.18e-38): exact scaling keeps their leading bits
+        den = base * 1e-39
+        assert bool((den.abs() < 1.2e-38).all()) and bool((den != 0).any())
+        Y = _run(scheme, den, W * 1e6)
+        ref = den.double() @ (W * 1e6).double()
+        assert float((Y.double() - ref).abs().max()) <= 2e-3 * float(ref.abs().max())   # 2^-10: few bits exist
+    else:
+        # the unscaled three-part scheme's envelope ends here: below ~1e-30 the second and third
+        # bf16 parts fall into the bf16 denormals (measured 2.5e-4 at 1e-37) — which is why the
+        # product path uses the scaled scheme; the error is still bounded by the first part's 2^-8
+        Y = _run(scheme, base * 1e-37, W * 1e3)
+        ref = (base * 1e-37).double() @ (W * 1e3).double()
+        assert float((Y.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
     # heavy cancellation: every row is (v, -v) against a W with duplicated rows -> the true result is
     # the rounding residue; the error must stay relative to the SUMMANDS' size, like torch.mm's
     v = torch.randn(M, 128, generator=gen, device=dev) * 100
@@ -111,13 +124,15 @@ def test_gemm_precision_at_the_edges_of_fp32(dev, scheme):
 
 
 def test_gemm_output_maximum_side_channel(dev):
-    """gcn_gemm_xw256_f32_h2 reports max|Y| (the next layer's bound) without a pass over Y."""
+    """gcn_gemm_xw256_f32_h2 reports max|Y| (the next layer's bound) without a pass over Y; and
+    without a caller-supplied bound the wrapper computes max|X| itself."""
     from pygcn_amd.spmm import gemm_xw256
     X = torch.randn(3000, 256, device=dev) * 3
     W = torch.randn(256, 256, device=dev)
     ymax = torch.zeros(1, device=dev)
     Y = gemm_xw256(X, W, x_bound=X.abs().max().reshape(1), y_absmax=ymax)
     assert float(ymax) == float(Y.abs().max())
+    assert torch.equal(gemm_xw256(X, W), Y)
 
 
 def test_gemm_declines_other_shapes(dev):
