@@ -371,7 +371,10 @@ class CSRGraph:
         dev = torch.device(device)
 
         def dev_t(a):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            import warnings
+            with warnings.catch_warnings():       # (read-only memory map: it is only copied from)
+                warnings.simplefilter("ignore", UserWarning)
+                return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
         def get(prefix, shape):
             g = cls(dev_t(arr[prefix + "rowptr"]), dev_t(arr[prefix + "col"]),
