@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 14
+#define GCN_ABI_VERSION 17
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -323,12 +323,43 @@ int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw,
  * max|X| (the tighter, the more of fp16's 2^17 usable dynamic range is kept below the maximum;
  * elements further below it lose relative — not absolute — precision).  y_absmax: optional DEVICE
  * float, zeroed by the caller, receives max|Y| (atomic max) — the bound a following layer needs.
+ * x_rows: optional DEVICE int32 list of M row indices — output row r is then the product of input
+ * row x_rows[r] (the gradient GEMMs run on the rows that can be non-zero without a compacting
+ * copy); NULL = rows 0 .. M-1.
  * Workspace >= gcn_gemm_xw256_h2_workspace_bytes().  `torch.mm(input, weight)`, pygcn/layers.py:33.
  */
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);
-int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y,
-                          int64_t ldy, int64_t M, const float *x_absmax_bound, float *y_absmax,
-                          void *workspace, size_t workspace_bytes, void *stream);
+int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                          int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
+                          float *y_absmax, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Y[M, N] = X[M, K] · W[K, N] for bf16 storage (config C5: 128 -> 128): bf16 in / out, fp32
+ * accumulate, (K, N) one of (128,128), (128,256), (256,128).  HBM-bound by construction (W resident in LDS, X streamed
+ * once, Y written once as 16-byte stores).  `torch.mm(input, weight)` (pygcn/layers.py:33) and
+ * the grad_input GEMM of its backward at bf16.  DEVICE pointers; rows 16-byte aligned; workspace
+ * >= gcn_gemm_bf16_workspace_bytes(K, N) (0 = unsupported shape).
+ */
+size_t gcn_gemm_bf16_workspace_bytes(int64_t K, int64_t N);
+int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, void *Y, int64_t ldy,
+                     int64_t M, int64_t K, int64_t N, void *workspace, size_t workspace_bytes,
+                     void *stream);
+
+/*
+ * out[256, 256] = Σ_{r < n_list} A[rows_a[r], :]ᵀ ⊗ G[rows_g[r], :]  — the weight gradient
+ * `inputᵀ · grad_support` of `torch.mm(input, weight)` (pygcn/layers.py:33; autograd of the call
+ * at pygcn/train.py:157) for 256-wide layers, fp32 in / out, over a LIST of rows: rows_a / rows_g
+ * are optional DEVICE int32 index lists (NULL = rows 0 .. n_list-1) naming the rows on which the
+ * gradient can be non-zero, so the operands need not be compacted first.  Scaled two-part fp16
+ * scheme as gcn_gemm_xw256_f32_h2 (a_absmax_bound / g_absmax_bound: DEVICE floats, upper bounds
+ * of max|A|, max|G| over the listed rows); partial products of row slabs are added in slab order
+ * (deterministic).  Workspace >= gcn_gemm_atg256_workspace_bytes(n_list).
+ */
+size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list);
+int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                        const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
+                        const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 14
+GCN_ABI_VERSION = 17
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -56,7 +56,9 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_bwd_colsum_workspace_bytes", "gcn_relu_dropout_backward_colsum",
            "gcn_log_softmax_backward_colsum", "gcn_plan_device_workspace_bytes",
            "gcn_plan_count_device", "gcn_plan_fill_device", "gcn_coo_to_csr_workspace_bytes",
-           "gcn_coo_to_csr_device", "gcn_gemm_xw256_h2_workspace_bytes", "gcn_gemm_xw256_f32_h2")
+           "gcn_coo_to_csr_device", "gcn_gemm_xw256_h2_workspace_bytes", "gcn_gemm_xw256_f32_h2",
+           "gcn_gemm_bf16_workspace_bytes", "gcn_gemm_xw_bf16",
+           "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32")
 
 _lib = None
 
@@ -162,9 +164,23 @@ def lib():
     L.gcn_gemm_xw256_h2_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_h2_workspace_bytes.argtypes = []
     L.gcn_gemm_xw256_f32_h2.restype = ctypes.c_int
-    L.gcn_gemm_xw256_f32_h2.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
-                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
-                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_gemm_xw256_f32_h2.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                        ctypes.c_void_p]
+    L.gcn_gemm_bf16_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_gemm_bf16_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
+    L.gcn_gemm_xw_bf16.restype = ctypes.c_int
+    L.gcn_gemm_xw_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_gemm_atg256_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_gemm_atg256_workspace_bytes.argtypes = [ctypes.c_int64]
+    L.gcn_gemm_atg256_f32.restype = ctypes.c_int
+    L.gcn_gemm_atg256_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_size_t, ctypes.c_void_p]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

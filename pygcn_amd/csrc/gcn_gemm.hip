@@ -34,6 +34,7 @@
 // (LDS-DMA for the W stream, staggered wave halves).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "gcn_spmm.h"
@@ -354,15 +355,17 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c)
 }
 
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
-    const float *__restrict__ X, int64_t ldx, const unsigned char *__restrict__ ws,
-    const float *__restrict__ x_bound, float *__restrict__ Y, int64_t ldy, int64_t M,
-    uint32_t *__restrict__ y_absmax)
+    const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
+    const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
+    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = (int64_t)blockIdx.x * kTileRows + 32 * wave + (lane & 31);
     const bool row_ok = row < M;
-    const float *xrow = X + (row_ok ? row : 0) * ldx + 8 * (lane >> 5);
+    // optional gather: output row `row` is the product of input row x_rows[row]
+    const int64_t src_row = row_ok ? (x_rows ? (int64_t)x_rows[row] : row) : 0;
+    const float *xrow = X + src_row * ldx + 8 * (lane >> 5);
     const unsigned char *wimg = ws + kH2HeaderBytes;
 
     // scales (wave-uniform scalars)
@@ -479,6 +482,234 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 storage (config C5): Y[M,N] = X[M,K] · W[K,N], bf16 in / out, fp32 accumulate, (K, N) in
+// {(128,128), (128,256), (256,128)} (256 x 256 would need more registers than two waves per SIMD
+// leave; it stays on hipBLASLt).  One bf16 MFMA per product — at 2·M·K·N flops against (K + N)·2 bytes per row this
+// kernel is bound by HBM, not by the matrix pipe (C5: 1.6 TFLOP vs 25.6 GB), so it is built as a
+// STREAM: the whole W (32–128 KiB, fragment-ordered by the prep kernel) is resident in LDS for the
+// lifetime of the workgroup, every wave walks its own 32-row tiles (grid-stride, no barrier after
+// the W load), the X fragments of the NEXT tile are in flight while the current one is multiplied
+// and stored, and the bf16 output rows leave as 16-byte stores (the two half-waves exchange their
+// 4-column groups with v_permlane32_swap first).
+template <int K, int N>
+__global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf16_kernel(const uint16_t *__restrict__ X, int64_t ldx,
+                                                        const uint16_t *__restrict__ wimg,
+                                                        uint16_t *__restrict__ Y, int64_t ldy,
+                                                        int64_t M, int64_t n_tiles)
+{
+    constexpr int KC = K / 16, NB = N / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];    // K * N * 2 bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const u32x4 *src = (const u32x4 *)wimg;
+        u32x4 *dst = (u32x4 *)wlds;
+        for (int i = tid; i < K * N * 2 / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= n_tiles) return;
+    const int r = lane & 31, h = lane >> 5;
+    u32x4 a_cur[KC], a_nxt[KC];
+    auto fetch = [&](int64_t tile, u32x4 (&dst)[KC]) {
+        int64_t row = tile * 32 + r;
+        row = row < M ? row : M - 1;                        // (clamped: the store is masked)
+        const u32x4 *p = (const u32x4 *)(X + row * ldx + 8 * h);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) dst[c] = p[2 * c];    // k = 16c + 8h .. +8
+    };
+    fetch(t, a_cur);
+    for (; t < n_tiles; t += stride) {
+        const bool more = t + stride < n_tiles;
+        if (more) fetch(t + stride, a_nxt);
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+        // (opaque per tile: otherwise hipcc hoists every W fragment out of the tile loop into
+        //  registers — 128..512 VGPRs — and the kernel runs at one wave per SIMD)
+        const unsigned char *wl = wlds;
+        asm volatile("" : "+v"(wl));
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const u32x4 b = *(const u32x4 *)(wl + ((c * NB + nb) * 64 + lane) * 16);
+                acc[nb] = mfma(b, a_cur[c], acc[nb]);      // transposed tile: lane = output row
+            }
+        }
+        const int64_t row = t * 32 + r;
+        if (row < M) {
+            unsigned char *yrow = (unsigned char *)(Y + row * ldy) + (h ? 16 : 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    // groups k = 4nb + g and k + 1: this lane's 4 columns of each, packed to bf16
+                    f32x2 p0 = {acc[nb][4 * g], acc[nb][4 * g + 1]}, p1 = {acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+                    f32x2 q0 = {acc[nb][4 * g + 4], acc[nb][4 * g + 5]}, q1 = {acc[nb][4 * g + 6], acc[nb][4 * g + 7]};
+                    uint32_t ax = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+                    uint32_t ay = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                    uint32_t bx = __builtin_bit_cast(uint32_t, __builtin_convertvector(q0, bf16x2));
+                    uint32_t by = __builtin_bit_cast(uint32_t, __builtin_convertvector(q1, bf16x2));
+                    auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    // lower half-wave: columns 8k .. 8k+7, upper: 8k+8 .. 8k+15 (16 bytes each)
+                    const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+                    *(u32x4 *)(yrow + (32 * nb + 8 * g) * 2) = v;
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < KC; ++c) a_cur[c] = a_nxt[c];
+        }
+    }
+}
+
+// W [K][N] bf16 row-major -> [chunk K/16][colblock N/32][lane 64][8 bf16]; element j of lane l:
+// k = 16*chunk + 8*(l>>5) + j, n = 32*cb + (l&31)
+__global__ __launch_bounds__(256) void order_w_bf16_kernel(const uint16_t *__restrict__ W, int64_t ldw,
+                                                           uint16_t *__restrict__ img, int K, int N)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nb_count = N / 32;
+    if (idx >= (K / 16) * nb_count * 64) return;
+    const int lane = idx & 63, cb = (idx >> 6) % nb_count, chunk = (idx >> 6) / nb_count;
+    const int n = 32 * cb + (lane & 31), k0 = 16 * chunk + 8 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) img[(size_t)idx * 8 + j] = W[(int64_t)(k0 + j) * ldw + n];
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: grad_W[256, 256] = Σ_r A[ra(r), :]ᵀ ⊗ G[rg(r), :]  over a LIST of rows
+// (`inputᵀ · grad_support`, the backward of pygcn/layers.py:33), fp32 in / out, scaled two-part
+// fp16 scheme (three MFMAs per product) like gemm_xw256_h2_kernel.
+//
+// The reduction runs over the graph's vertices, so both operands are "k-major" for the MFMA: a
+// lane needs 8 consecutive ROWS of one column.  Instead of a transpose through LDS the fragments
+// are loaded as they are needed — 8 dword loads per lane and fragment, each a coalesced 128-byte
+// row segment per half-wave — which also makes the row GATHER free: ra / rg are optional index
+// lists (the rows on which the gradient can be non-zero, pygcn_amd/fused.py), so the compacting
+// index_select copies of both operands disappear.  Wave w of the 8 owns output rows 32w..32w+31
+// (columns of A) against all 256 columns of G; per 16-row step every wave loads and splits ONE
+// fragment of A for itself and ONE fragment of G for everybody (LDS, double-buffered, one barrier
+// per step).  The row list is cut into slabs, one per workgroup; the slabs' partial products are
+// added in slab order by a second kernel (deterministic, no atomics).
+constexpr int kAtgStepsMin = 8;                 // at least this many 16-row steps per workgroup
+constexpr int kAtgMaxWgs = 256;
+
+__global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
+    const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
+    const float *__restrict__ G, int64_t ldg, const int32_t *__restrict__ rg, int64_t n_list,
+    const float *__restrict__ a_bound, const float *__restrict__ g_bound,
+    float *__restrict__ partial, int64_t steps_per_wg)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 8 * 2 * kFragBytes];   // 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    auto scale_exp = [](float b) {
+        int e = 14 - floor_log2f(b);
+        e = e > 126 ? 126 : (e < -126 ? -126 : e);
+        return (!(b > 0.f) || !(b <= 3.4028235e38f)) ? 0 : e;
+    };
+    const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
+    const float as = pow2f(a_exp), gs = pow2f(g_exp);
+    const int back = -(a_exp + g_exp);
+    const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[jb][i] = 0.f;
+
+    const int64_t s0 = (int64_t)blockIdx.x * steps_per_wg;
+    const int64_t total_steps = (n_list + 15) >> 4;
+    const int64_t s1 = s0 + steps_per_wg < total_steps ? s0 + steps_per_wg : total_steps;
+    const float *acol = A + 32 * wave + c, *gcol = G + 32 * wave + c;
+
+    float av[2][8], gv[2][8];
+    auto fetch = [&](int64_t step, float (&a)[8], float (&g)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t r = step * 16 + 8 * h + j;
+            const bool ok = r < n_list;
+            const int64_t rr = ok ? r : 0;
+            const int64_t ia = ra ? (int64_t)ra[rr] : rr, ig = rg ? (int64_t)rg[rr] : rr;
+            const float x = acol[ia * lda], y = gcol[ig * ldg];
+            a[j] = ok ? x * as : 0.f;
+            g[j] = ok ? y * gs : 0.f;
+        }
+    };
+    auto split8 = [&](const float (&v)[8], u32x4 &hi, u32x4 &lo) {
+        uint32_t hh[4], mm[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2 p = {v[2 * j], v[2 * j + 1]};
+            const h16x2 ph = __builtin_convertvector(p, h16x2);
+            const f32x2 pb = __builtin_convertvector(ph, f32x2);
+            f32x2 q = {p.x - pb.x, p.y - pb.y};
+            const h16x2 pm = __builtin_convertvector(q, h16x2);
+            hh[j] = __builtin_bit_cast(uint32_t, ph);
+            mm[j] = __builtin_bit_cast(uint32_t, pm);
+        }
+        hi = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        lo = u32x4{mm[0], mm[1], mm[2], mm[3]};
+    };
+
+    if (s0 < s1) fetch(s0, av[0], gv[0]);
+    for (int64_t s = s0; s < s1; ++s) {
+        const int cur = (int)((s - s0) & 1);
+        u32x4 Ah, Am, Gh, Gm;
+        if (cur == 0) {
+            split8(av[0], Ah, Am);
+            split8(gv[0], Gh, Gm);
+            if (s + 1 < s1) fetch(s + 1, av[1], gv[1]);
+        } else {
+            split8(av[1], Ah, Am);
+            split8(gv[1], Gh, Gm);
+            if (s + 1 < s1) fetch(s + 1, av[0], gv[0]);
+        }
+        unsigned char *buf = lds + cur * (8 * 2 * kFragBytes);
+        *(u32x4 *)(buf + ((wave * 2 + 0) * 64 + lane) * 16) = Gh;
+        *(u32x4 *)(buf + ((wave * 2 + 1) * 64 + lane) * 16) = Gm;
+        __syncthreads();
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            const u32x4 Bh = *(const u32x4 *)(buf + ((jb * 2 + 0) * 64 + lane) * 16);
+            const u32x4 Bm = *(const u32x4 *)(buf + ((jb * 2 + 1) * 64 + lane) * 16);
+            f32x16 t = acc[jb];
+            t = mfma_h(Am, Bh, t);
+            t = mfma_h(Ah, Bm, t);
+            t = mfma_h(Ah, Bh, t);
+            acc[jb] = t;
+        }
+    }
+    // D[i][j]: i = 32*wave + (reg&3) + 8*(reg>>2) + 4*h, j = 32*jb + c
+    float *out = partial + (size_t)blockIdx.x * (kK * kN);
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            out[i * kN + 32 * jb + c] = acc[jb][reg] * back_a * back_b;
+        }
+}
+
+__global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict__ partial, int n_wg,
+                                                         float *__restrict__ out, int64_t ldo)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // one output element
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += partial[(size_t)w * (kK * kN) + idx];
+    out[(int64_t)(idx >> 8) * ldo + (idx & 255)] = s;
+}
+
 }   // namespace
 
 extern "C" {
@@ -514,9 +745,9 @@ size_t gcn_gemm_xw256_h2_workspace_bytes(void)
     return (size_t)kH2HeaderBytes + (size_t)kChunks * kH2ChunkBytes;
 }
 
-int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const float *W, int64_t ldw, float *Y,
-                          int64_t ldy, int64_t M, const float *x_absmax_bound, float *y_absmax,
-                          void *workspace, size_t workspace_bytes, void *stream)
+int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                          int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
+                          float *y_absmax, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
@@ -532,10 +763,101 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const float *W, int64_t l
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
     hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
-                       (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                       x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                        (uint32_t *)y_absmax);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
+    return 0;
+}
+
+size_t gcn_gemm_bf16_workspace_bytes(int64_t K, int64_t N)
+{
+    if ((K != 128 && K != 256) || (N != 128 && N != 256) || (K == 256 && N == 256)) return 0;
+    return (size_t)K * (size_t)N * 2;
+}
+
+int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, void *Y, int64_t ldy,
+                     int64_t M, int64_t K, int64_t N, void *workspace, size_t workspace_bytes,
+                     void *stream)
+{
+    const size_t need = gcn_gemm_bf16_workspace_bytes(K, N);
+    if (need == 0)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: (K, N) must be (128,128), (128,256) or (256,128)");
+    if (M < 0 || ldx < K || ldy < N || ldw < N)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: bad sizes");
+    if (M == 0) return 0;
+    if (X == nullptr || W == nullptr || Y == nullptr || workspace == nullptr)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: NULL pointer");
+    if (workspace_bytes < need)
+        return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw_bf16: workspace too small");
+    if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 8) != 0 ||
+        (ldy % 8) != 0)
+        return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: X / Y rows must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int frags = (int)((K / 16) * (N / 32) * 64);
+    hipLaunchKernelGGL(order_w_bf16_kernel, dim3((frags + 255) / 256), dim3(256), 0, s,
+                       (const uint16_t *)W, ldw, (uint16_t *)workspace, (int)K, (int)N);
+    const int64_t tiles = (M + 31) / 32;
+    // resident workgroups per CU: LDS (160 KiB / image) and registers allow 3 (128 x 128) … 1
+    const int per_cu = need <= 32 * 1024 ? 3 : (need <= 64 * 1024 ? 2 : 1);
+    const unsigned grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, (int64_t)256 * per_cu);
+#define GCN_LAUNCH_BF16(KK, NN)                                                                     \
+    do {                                                                                            \
+        hipError_t ae = hipFuncSetAttribute((const void *)gemm_bf16_kernel<KK, NN>,                \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); \
+        if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw_bf16: LDS size"); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<KK, NN>), dim3(grid), dim3(256), need, s,              \
+                           (const uint16_t *)X, ldx, (const uint16_t *)workspace, (uint16_t *)Y,   \
+                           ldy, M, tiles);                                                          \
+    } while (0)
+    if (K == 128 && N == 128) GCN_LAUNCH_BF16(128, 128);
+    else if (K == 128 && N == 256) GCN_LAUNCH_BF16(128, 256);
+    else GCN_LAUNCH_BF16(256, 128);
+#undef GCN_LAUNCH_BF16
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw_bf16 launch");
+    return 0;
+}
+
+static int64_t atg_wgs(int64_t n_list)
+{
+    const int64_t steps = (n_list + 15) / 16;
+    return std::max<int64_t>(1, std::min<int64_t>(kAtgMaxWgs, (steps + kAtgStepsMin - 1) / kAtgStepsMin));
+}
+
+size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list)
+{
+    if (n_list <= 0) return 256;
+    return (size_t)atg_wgs(n_list) * (size_t)(kK * kN) * sizeof(float);
+}
+
+int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                        const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
+                        const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    if (n_list < 0 || lda < kK || ldg < kN || ldo < kN)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: bad sizes");
+    if (out == nullptr) return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL output");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_list == 0) {
+        hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)kN * 4, kK, s);
+        return e == hipSuccess ? 0 : gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32: memset");
+    }
+    if (A == nullptr || G == nullptr || a_absmax_bound == nullptr || g_absmax_bound == nullptr ||
+        workspace == nullptr)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL pointer");
+    if (workspace_bytes < gcn_gemm_atg256_workspace_bytes(n_list))
+        return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_atg256_f32: workspace too small");
+    const int64_t n_wg = atg_wgs(n_list);
+    const int64_t steps = (n_list + 15) / 16;
+    const int64_t per = (steps + n_wg - 1) / n_wg;
+    hipLaunchKernelGGL(gemm_atg256_h2_kernel, dim3((unsigned)n_wg), dim3(512), 0, s, A, lda, rows_a, G,
+                       ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
+    hipLaunchKernelGGL(atg_reduce_kernel, dim3(kK * kN / 256), dim3(256), 0, s, (const float *)workspace,
+                       (int)n_wg, out, ldo);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32 launch");
     return 0;
 }
 

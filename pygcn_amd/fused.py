@@ -69,6 +69,7 @@ class RowSets:
             torch.arange(total, device=dev)
         self.rows2 = torch.unique(graph.col[idx].to(torch.int64))                # sorted
         self.n2 = int(self.rows2.numel())
+        self.rows2_i32 = self.rows2.to(torch.int32)
         mask2 = torch.zeros(graph.shape[1], dtype=torch.bool, device=dev)
         mask2[self.rows2] = True
         self.hint2 = pack_row_flags(mask2)
@@ -136,6 +137,7 @@ class GCN2RowsFunction(torch.autograd.Function):
             if b1 is not None:
                 h_bound = h_bound + b1.detach().abs().max().float()
             h_bound = h_bound * (1.0001 * ctx.scale)
+        ctx.h_bound = h_bound
         logp = spmm_csr(graph, _dense_forward(h1, w2, h_bound), bias=b2, log_softmax=True)
         out_rows = logp.index_select(0, rows.to(torch.int64))
         ctx.save_for_backward(x, w1, w2, h1, out_rows)
@@ -170,39 +172,52 @@ class GCN2RowsFunction(torch.autograd.Function):
         grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
         grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd", b_hint=rs.hint, c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, gp.shape[1]), dt, dev))
-        gs2 = grad_sup2.index_select(0, rs.rows2)           # [|R2|, C]
-        del grad_pre2, grad_sup2
-        h1c = h1.index_select(0, rs.rows2)                  # [|R2|, H]
-        if need_w2:
-            grad_w2 = _weight_grad(h1c, gs2)
         # |Âᵀ·grad_pre2| <= ‖Âᵀ‖∞ · max|grad_pre2|  (max over the small [|R|, C] tensor)
-        gs_bound = graph_t.inf_norm() * gp.abs().max().float() * 1.0001 if dt == torch.float32 else None
-        gh1 = gemm_xw256(gs2, w2.t().contiguous(), gs_bound)
+        f32 = dt == torch.float32
+        gs_bound = graph_t.inf_norm() * torch.linalg.vector_norm(gp, ord=float("inf")) * 1.0001 \
+            if f32 else None
+        h1c = h1.index_select(0, rs.rows2)                  # [|R2|, H] (the ReLU / dropout mask)
+        # the GEMMs read the rows R2 of grad_sup2 / h1 in place (row lists), no compacting copies
+        fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
+        gs2 = None
+        if need_w2:
+            grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_i32, rs.rows2_i32, ctx.h_bound,
+                                             gs_bound) if fast else None
+            if grad_w2 is None:
+                gs2 = grad_sup2.index_select(0, rs.rows2)
+                grad_w2 = _weight_grad(h1c, gs2)
+        gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
+        w2t = w2.t().contiguous()
+        gh1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, rows=rs.rows2_i32) if fast else None
         if gh1 is None:
-            gh1 = torch.mm(gs2, w2.t())
-        del gs2
+            gs2 = grad_sup2.index_select(0, rs.rows2) if gs2 is None else gs2
+            gh1 = _dense_forward(gs2, w2t, gs_bound, gh_max)
+        del gs2, grad_pre2, grad_sup2
         # ---- ReLU / dropout mask on the compact rows (out > 0 encodes ReLU and keep)
         gpre1 = torch.where(h1c > 0, gh1 * ctx.scale if ctx.scale != 1.0 else gh1,
                             torch.zeros((), dtype=dt, device=dev))
         del gh1, h1c
         if ctx.has_bias[0] and need_b1:
             grad_b1 = gpre1.float().sum(0).to(ctx.bias_dtypes[0])
+        gpre_bound = gh_max * ctx.scale if f32 else None
         # ---- layer 1
         if not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
             if need_w1:
                 # grad_W1 = (Â·X)[R2]ᵀ · grad_pre1[R2]: a forward product restricted to rows R2
                 z = spmm_csr(graph, x, tag="bwd", c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
-                grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
+                if f32 and _spmm._gemm_scheme == "h2" and x.shape[1] == 256 and gpre1.shape[1] == 256:
+                    z_bound = graph.inf_norm() * _spmm.absmax_cached(x) * 1.0001
+                    grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_i32, None, z_bound, gpre_bound)
+                if grad_w1 is None:
+                    grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
         elif need_x or need_w1:
             grad_pre1 = _operand_buffer(n, gpre1.shape[1], dt, dev, rs.rows2, gpre1, rs.n2)
             grad_sup1 = spmm_csr(graph_t, grad_pre1, tag="bwd", b_hint=rs.hint2)
             if need_w1:
                 grad_w1 = _weight_grad(x, grad_sup1)
             if need_x:
-                grad_x = gemm_xw256(grad_sup1, w1.t().contiguous())
-                if grad_x is None:
-                    grad_x = torch.mm(grad_sup1, w1.t())
+                grad_x = _dense_forward(grad_sup1, w1.t().contiguous())
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
 
 

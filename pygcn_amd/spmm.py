@@ -336,7 +336,7 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
-def gemm_xw256(X, W, x_bound=None, y_absmax=None):
+def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -345,7 +345,8 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None):
     three MFMAs per product.  `x_bound` (DEVICE float tensor [1]) is any upper bound of max|X|; if
     the caller has none, max|X| is computed here by one reduction pass.  `y_absmax` (DEVICE float
     tensor [1], zeroed by the caller) receives max|Y|, from which a layer derives the next bound
-    without a pass over the data.
+    without a pass over the data.  `rows` (int32 device list): output row r is the product of
+    input row rows[r] — a gather fused into the kernel's loads.
     Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
     product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
     underflow — tests/test_gemm_gpu.py)."""
@@ -354,7 +355,15 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None):
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
-    Y = torch.empty((X.shape[0], 256), dtype=torch.float32, device=X.device)
+    if rows is not None:
+        if _gemm_scheme != "h2":
+            X, rows = X.index_select(0, rows.long()), None
+        elif rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != X.device:
+            raise RuntimeError("gemm_xw256: rows must be a contiguous int32 device tensor")
+    m_out = rows.numel() if rows is not None else X.shape[0]
+    Y = torch.empty((m_out, 256), dtype=torch.float32, device=X.device)
+    if m_out == 0:
+        return Y
     if x_bound is None and _gemm_scheme == "h2":
         # no bound known: one reduction pass over X (1.4 ms at M = 10^7) and the 5.4 ms kernel
         # still beat the 7.5 ms three-part kernel — and keep full accuracy for tiny operands,
@@ -367,8 +376,10 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None):
                 raise RuntimeError("gemm_xw256: x_bound must be one float32 on the operand's device")
             ws_bytes = L.gcn_gemm_xw256_h2_workspace_bytes()
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
-            rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0),
-                                         Y.data_ptr(), Y.stride(0), X.shape[0], x_bound.data_ptr(),
+            rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0),
+                                         rows.data_ptr() if rows is not None else None,
+                                         W.data_ptr(), W.stride(0),
+                                         Y.data_ptr(), Y.stride(0), m_out, x_bound.data_ptr(),
                                          y_absmax.data_ptr() if y_absmax is not None else None,
                                          ws.data_ptr(), ws_bytes, stream)
             _native.check(rc, "gcn_gemm_xw256_f32_h2")
@@ -381,6 +392,66 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None):
     if y_absmax is not None:
         y_absmax.copy_(Y.abs().max())
     return Y
+
+
+def gemm_bf16(X, W):
+    """X[M,K] · W[K,N] for bf16 storage through the streaming MFMA kernel (C-ABI gcn_gemm_xw_bf16;
+    (K, N) in {(128,128), (128,256), (256,128)} — config C5's layers are 128 -> 128).  None if the
+    operands do not fit (the caller then uses torch.mm)."""
+    if (X.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not X.is_cuda or X.dim() != 2
+            or W.dim() != 2 or X.shape[1] != W.shape[0] or X.shape[0] == 0 or X.stride(1) != 1
+            or W.stride(1) != 1 or X.stride(0) % 8 or X.data_ptr() % 16):
+        return None
+    L = _native.lib()
+    K, N = W.shape
+    ws_bytes = L.gcn_gemm_bf16_workspace_bytes(K, N)
+    if ws_bytes == 0:
+        return None
+    Y = torch.empty((X.shape[0], N), dtype=torch.bfloat16, device=X.device)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    with torch.cuda.device(X.device):
+        rc = L.gcn_gemm_xw_bf16(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), Y.data_ptr(),
+                                Y.stride(0), X.shape[0], K, N, ws.data_ptr(), ws_bytes,
+                                torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_gemm_xw_bf16")
+    return Y
+
+
+def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None):
+    """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] -> [256, 256] through the gather-fused MFMA kernel (C-ABI
+    gcn_gemm_atg256_f32): the weight gradient `inputᵀ · grad_support` over a LIST of rows, without
+    compacting either operand first.  rows_*: int32 device index lists or None (= all rows, in
+    order; both operands must then list the same number of rows).  *_bound: DEVICE float [1] upper
+    bounds of max|A|, max|G| (computed here by a reduction pass when missing).  None if the
+    operands do not fit the kernel (fp32, 256 columns each)."""
+    if (A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda or A.dim() != 2
+            or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
+            or G.stride(1) != 1):
+        return None
+    n_a = rows_a.numel() if rows_a is not None else A.shape[0]
+    n_g = rows_g.numel() if rows_g is not None else G.shape[0]
+    if n_a != n_g:
+        raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
+    for r in (rows_a, rows_g):
+        if r is not None and (r.dtype != torch.int32 or not r.is_contiguous() or r.device != A.device):
+            raise RuntimeError("weight_grad_rows: row lists must be contiguous int32 device tensors")
+    if a_bound is None:
+        a_bound = torch.linalg.vector_norm(A.detach(), ord=float("inf")).reshape(1)
+    if g_bound is None:
+        g_bound = torch.linalg.vector_norm(G.detach(), ord=float("inf")).reshape(1)
+    L = _native.lib()
+    out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
+    ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_a)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = L.gcn_gemm_atg256_f32(A.data_ptr(), A.stride(0),
+                                   rows_a.data_ptr() if rows_a is not None else None,
+                                   G.data_ptr(), G.stride(0),
+                                   rows_g.data_ptr() if rows_g is not None else None, n_a,
+                                   a_bound.data_ptr(), g_bound.data_ptr(), out.data_ptr(), out.stride(0),
+                                   ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_gemm_atg256_f32")
+    return out
 
 
 _gemm_scheme = "h2"
@@ -410,6 +481,8 @@ def absmax_cached(t):
 
 def _dense_forward(input, weight, x_bound=None, y_absmax=None):
     out = gemm_xw256(input, weight, x_bound, y_absmax)
+    if out is None and y_absmax is None:
+        out = gemm_bf16(input, weight)
     if out is None:
         out = torch.mm(input, weight)
         if y_absmax is not None:
@@ -422,7 +495,12 @@ MIN_ROWS = 1 << 17     # below this the plain GEMMs are launch-bound anyway
 
 
 def _weight_grad(input, grad):
-    """inputᵀ · grad with the reduction over the graph's vertices cut into K_SPLIT slabs."""
+    """inputᵀ · grad: the hand-written MFMA kernel for 256-wide fp32 layers, otherwise hipBLASLt
+    with the reduction over the graph's vertices cut into K_SPLIT slabs."""
+    if input.shape[0] >= 4096 and _gemm_scheme == "h2":
+        out = weight_grad_rows(input, grad)
+        if out is not None:
+            return out
     n, b = input.shape[0], K_SPLIT
     if n >= MIN_ROWS and input.is_contiguous() and grad.is_contiguous():
         m = n // b * b
@@ -446,6 +524,8 @@ def _dense_grads(input, weight, grad, need_in, need_w, rows=None):
         if need_in:
             part = gemm_xw256(grad, weight.t().contiguous())
             if part is None:
+                part = gemm_bf16(grad, weight.t().contiguous())
+            if part is None:
                 part = torch.mm(grad, weight.t())
             grad_in = torch.zeros((input.shape[0], weight.shape[0]), dtype=part.dtype,
                                   device=part.device)
@@ -453,6 +533,8 @@ def _dense_grads(input, weight, grad, need_in, need_w, rows=None):
         return grad_in, grad_w
     if need_in:
         grad_in = gemm_xw256(grad, weight.t().contiguous())
+        if grad_in is None:
+            grad_in = gemm_bf16(grad, weight.t().contiguous())
         if grad_in is None:
             grad_in = torch.mm(grad, weight.t())
     if need_w:

@@ -167,3 +167,83 @@ def test_layer_256_to_256_through_custom_gemm(oracle, dev):
     assert_normwise(xg.grad.cpu(), gx, 1e-5, "grad_x")
     assert_normwise(layer.weight.grad.cpu(), gw, 2e-5, "grad_w")
     assert_normwise(layer.bias.grad.cpu(), gb, 2e-5, "grad_b")
+
+
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 100, 4097, 70001])
+def test_weight_gradient_over_row_lists_matches_fp64(dev, M):
+    """gcn_gemm_atg256_f32: Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] with and without row lists (the weight
+    gradient of pygcn/layers.py:33 over the rows on which the gradient can be non-zero)."""
+    from pygcn_amd.spmm import weight_grad_rows
+    gen = torch.Generator(device=dev).manual_seed(M)
+    n_a, n_g = 3 * M + 5, 2 * M + 3
+    A = torch.randn(n_a, 256, generator=gen, device=dev) * 3
+    G = torch.randn(n_g, 256, generator=gen, device=dev) * 0.01
+    ra = torch.randint(0, n_a, (M,), generator=gen, device=dev).to(torch.int32)
+    rg = torch.randperm(n_g, generator=gen, device=dev)[:M].to(torch.int32)
+    got = weight_grad_rows(A, G, ra, rg)
+    ref = A[ra.long()].double().t() @ G[rg.long()].double()
+    summands = float((A[ra.long()].abs().double().t() @ G[rg.long()].abs().double()).max())
+    assert got.shape == (256, 256)
+    assert float((got.double() - ref).abs().max()) <= 3e-7 * summands
+    torch_err = float(((A[ra.long()].t() @ G[rg.long()]).double() - ref).abs().max())
+    assert float((got.double() - ref).abs().max()) <= 4 * torch_err + 1e-7 * summands
+    # one list only / no list, strided operands, and bitwise determinism
+    Ac = A[ra.long()].contiguous()
+    assert torch.equal(weight_grad_rows(Ac, G, None, rg), got)
+    wide = torch.randn(M, 512, generator=gen, device=dev)
+    g2 = weight_grad_rows(Ac, wide[:, 256:])
+    ref2 = Ac.double().t() @ wide[:, 256:].double()
+    assert float((g2.double() - ref2).abs().max()) <= 3e-7 * float((Ac.abs().double().t() @ wide[:, 256:].abs().double()).max())
+    assert torch.equal(weight_grad_rows(Ac, wide[:, 256:]), g2)
+    # rows outside the list must not be read: poison them
+    Ap = torch.full_like(A, float("nan"))
+    Ap[ra.long()] = A[ra.long()]
+    assert torch.equal(weight_grad_rows(Ap, G, ra, rg), got)
+
+
+def test_weight_gradient_degenerate_lists(dev):
+    from pygcn_amd.spmm import weight_grad_rows
+    A, G = torch.randn(10, 256, device=dev), torch.randn(10, 256, device=dev)
+    empty = torch.empty(0, dtype=torch.int32, device=dev)
+    assert bool((weight_grad_rows(A, G, empty, empty) == 0).all())
+    with pytest.raises(RuntimeError, match="different numbers of rows"):
+        weight_grad_rows(A, G, empty, None)
+    assert weight_grad_rows(A[:, :128], G) is None
+
+
+def test_gemm_with_row_list(dev):
+    """gcn_gemm_xw256_f32_h2 with x_rows: output row r = X[rows[r]] · W, unlisted rows never read."""
+    from pygcn_amd.spmm import gemm_xw256
+    X = torch.randn(5000, 256, device=dev)
+    W = torch.randn(256, 256, device=dev)
+    rows = torch.randperm(5000, device=dev)[:1237].to(torch.int32)
+    want = gemm_xw256(X[rows.long()].contiguous(), W, x_bound=X.abs().max().reshape(1))
+    Xp = torch.full_like(X, float("nan"))
+    Xp[rows.long()] = X[rows.long()]
+    got = gemm_xw256(Xp, W, x_bound=X.abs().max().reshape(1), rows=rows)
+    assert got.shape == (1237, 256) and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128)])
+@pytest.mark.parametrize("M", [1, 33, 1000, 65537])
+def test_bf16_gemm_matches_fp32_on_rounded_inputs(dev, K, N, M):
+    """gcn_gemm_xw_bf16 (config C5: 128 -> 128): bf16 products are exact in fp32, so against an fp64
+    product of the same bf16 inputs only the fp32 accumulation and the final rounding to bf16
+    (2^-9 relative) differ."""
+    from pygcn_amd.spmm import gemm_bf16
+    gen = torch.Generator(device=dev).manual_seed(K + N + M)
+    X = torch.randn(M, K, generator=gen, device=dev).bfloat16()
+    W = (torch.randn(K, N, generator=gen, device=dev) * 0.2).bfloat16()
+    Y = gemm_bf16(X, W)
+    assert Y is not None and Y.dtype == torch.bfloat16 and Y.shape == (M, N)
+    ref = X.double() @ W.double()
+    err = (Y.double() - ref).abs()
+    assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-5 * float(ref.abs().max())).all())
+    assert torch.equal(Y, gemm_bf16(X, W))
+    # the same numbers as torch.mm at bf16 up to the final rounding
+    assert float((Y.float() - (X @ W).float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    wide = torch.randn(M, 2 * K, generator=gen, device=dev).bfloat16()
+    Ys = gemm_bf16(wide[:, K:], W)                       # strided rows
+    refs = wide[:, K:].double() @ W.double()
+    assert bool(((Ys.double() - refs).abs() <= 2.0 ** -8 * refs.abs() + 1e-5 * float(refs.abs().max())).all())
+    assert gemm_bf16(X[:, :64], W[:64]) is None and gemm_bf16(X.float(), W.float()) is None
