@@ -435,10 +435,13 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None)
     for r in (rows_a, rows_g):
         if r is not None and (r.dtype != torch.int32 or not r.is_contiguous() or r.device != A.device):
             raise RuntimeError("weight_grad_rows: row lists must be contiguous int32 device tensors")
+    # (no bound supplied: a reduction pass — over the LISTED rows only, the others may hold anything)
     if a_bound is None:
-        a_bound = torch.linalg.vector_norm(A.detach(), ord=float("inf")).reshape(1)
+        src = A.detach() if rows_a is None else A.detach().index_select(0, rows_a.long())
+        a_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
     if g_bound is None:
-        g_bound = torch.linalg.vector_norm(G.detach(), ord=float("inf")).reshape(1)
+        src = G.detach() if rows_g is None else G.detach().index_select(0, rows_g.long())
+        g_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
     L = _native.lib()
     out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
     ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_a)
