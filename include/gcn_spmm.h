@@ -349,8 +349,9 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
  * out[256, 256] = Σ_{r < n_list} A[rows_a[r], :]ᵀ ⊗ G[rows_g[r], :]  — the weight gradient
  * `inputᵀ · grad_support` of `torch.mm(input, weight)` (pygcn/layers.py:33; autograd of the call
  * at pygcn/train.py:157) for 256-wide layers, fp32 in / out, over a LIST of rows: rows_a / rows_g
- * are optional DEVICE int32 index lists (NULL = rows 0 .. n_list-1) naming the rows on which the
- * gradient can be non-zero, so the operands need not be compacted first.  Scaled two-part fp16
+ * are DEVICE int32 index lists naming the rows on which the gradient can be non-zero (an identity
+ * list for "all rows"), so the operands need not be compacted first; a list must be PADDED to a
+ * multiple of 16 entries with valid indices (n_list counts the real ones).  Scaled two-part fp16
  * scheme as gcn_gemm_xw256_f32_h2 (a_absmax_bound / g_absmax_bound: DEVICE floats, upper bounds
  * of max|A|, max|G| over the listed rows); partial products of row slabs are added in slab order
  * (deterministic).  Workspace >= gcn_gemm_atg256_workspace_bytes(n_list).

@@ -586,22 +586,26 @@ __global__ __launch_bounds__(256) void order_w_bf16_kernel(const uint16_t *__res
 
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradient: grad_W[256, 256] = Σ_r A[ra(r), :]ᵀ ⊗ G[rg(r), :]  over a LIST of rows
+// Weight gradient: grad_W[256, 256] = Σ_r A[ra[r], :]ᵀ ⊗ G[rg[r], :]  over a LIST of rows
 // (`inputᵀ · grad_support`, the backward of pygcn/layers.py:33), fp32 in / out, scaled two-part
 // fp16 scheme (three MFMAs per product) like gemm_xw256_h2_kernel.
 //
 // The reduction runs over the graph's vertices, so both operands are "k-major" for the MFMA: a
-// lane needs 8 consecutive ROWS of one column.  Instead of a transpose through LDS the fragments
-// are loaded as they are needed — 8 dword loads per lane and fragment, each a coalesced 128-byte
-// row segment per half-wave — which also makes the row GATHER free: ra / rg are optional index
-// lists (the rows on which the gradient can be non-zero, pygcn_amd/fused.py), so the compacting
-// index_select copies of both operands disappear.  Wave w of the 8 owns output rows 32w..32w+31
-// (columns of A) against all 256 columns of G; per 16-row step every wave loads and splits ONE
-// fragment of A for itself and ONE fragment of G for everybody (LDS, double-buffered, one barrier
-// per step).  The row list is cut into slabs, one per workgroup; the slabs' partial products are
-// added in slab order by a second kernel (deterministic, no atomics).
+// lane needs 8 consecutive ROWS of one column.  No transpose through LDS is needed: a wave loads
+// 64 consecutive columns of ONE row per instruction (256 contiguous bytes, row address on the
+// scalar unit — which makes the row GATHER free: ra / rg list the rows on which the gradient can
+// be non-zero, pygcn_amd/fused.py), 16 rows per step; register j then holds row j and register
+// 8+j row 8+j of columns [0,32 | 32,64), and ONE v_permlane32_swap per pair turns them into the
+// two 32-column MFMA fragments (lanes < 32: k = j, lanes >= 32: k = 8 + j).  Waves 0-3 load, split
+// and publish the A fragments (64 columns each), waves 4-7 the G fragments (LDS, double-buffered,
+// one barrier per step); every wave then multiplies its 64 x 128 block of the result (2 x 4 tiles).
+// Loads run kAtgDepth steps ahead in a register ring.  The row list is cut into slabs, one per
+// workgroup; the slabs' partial products are added in slab order by a second kernel
+// (deterministic, no atomics).  Index lists are padded to a multiple of 16 entries with valid
+// indices (n_list counts the real entries): the 16 indices of a step are one scalar load.
 constexpr int kAtgStepsMin = 8;                 // at least this many 16-row steps per workgroup
 constexpr int kAtgMaxWgs = 256;
+constexpr int kAtgDepth = 3;
 
 __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
@@ -609,96 +613,124 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const float *__restrict__ a_bound, const float *__restrict__ g_bound,
     float *__restrict__ partial, int64_t steps_per_wg)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 8 * 2 * kFragBytes];   // 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
+    // [buffer 2][operand 2 (A, G)][32-column block 8][split 2][lane 64][16 B] = 64 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 8 * 2 * kFragBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, loads_g = wave >> 2;       // column group; waves 4-7 stream G
+    const int iw = wave & 3, jh = wave >> 2;            // result block: rows 64iw.., columns 128jh..
     auto scale_exp = [](float b) {
         int e = 14 - floor_log2f(b);
         e = e > 126 ? 126 : (e < -126 ? -126 : e);
         return (!(b > 0.f) || !(b <= 3.4028235e38f)) ? 0 : e;
     };
     const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
-    const float as = pow2f(a_exp), gs = pow2f(g_exp);
+    const float my_scale = pow2f(loads_g ? g_exp : a_exp);
     const int back = -(a_exp + g_exp);
     const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);
 
-    f32x16 acc[8];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+    for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[jb][i] = 0.f;
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ib][jb][i] = 0.f;
 
     const int64_t s0 = (int64_t)blockIdx.x * steps_per_wg;
     const int64_t total_steps = (n_list + 15) >> 4;
     const int64_t s1 = s0 + steps_per_wg < total_steps ? s0 + steps_per_wg : total_steps;
-    const float *acol = A + 32 * wave + c, *gcol = G + 32 * wave + c;
+    // the operand this wave streams: 64 columns of it
+    const float *src = (loads_g ? G : A) + 64 * cg + lane;
+    const int64_t ld = loads_g ? ldg : lda;
+    const int32_t *rows = loads_g ? rg : ra;
 
-    float av[2][8], gv[2][8];
-    auto fetch = [&](int64_t step, float (&a)[8], float (&g)[8]) {
+    float ring[kAtgDepth][16];
+    auto fetch = [&](int64_t step, float (&v)[16]) {     // loads only — no arithmetic on the results
+        const int32_t *idx = rows + step * 16;           // (wave-uniform: scalar loads)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld];
+    };
+    auto publish = [&](int64_t step, float (&v)[16], unsigned char *buf) {
+        // scale, zero the rows past the end of the list, swap halves into the two fragments,
+        // split each into (h, m) fp16 parts, store to this wave's four LDS slots
+        uint32_t hh[2][4], mm[2][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t r = step * 16 + 8 * h + j;
-            const bool ok = r < n_list;
-            const int64_t rr = ok ? r : 0;
-            const int64_t ia = ra ? (int64_t)ra[rr] : rr, ig = rg ? (int64_t)rg[rr] : rr;
-            const float x = acol[ia * lda], y = gcol[ig * ldg];
-            a[j] = ok ? x * as : 0.f;
-            g[j] = ok ? y * gs : 0.f;
+            const float lo_k = (step * 16 + j < n_list) ? v[j] * my_scale : 0.f;
+            const float hi_k = (step * 16 + 8 + j < n_list) ? v[8 + j] * my_scale : 0.f;
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_k), __float_as_uint(hi_k),
+                                                       false, false);
+            v[j] = __uint_as_float(sw[0]);               // columns 0-31 of the group:  k = 8h + j
+            v[8 + j] = __uint_as_float(sw[1]);           // columns 32-63 of the group: k = 8h + j
         }
-    };
-    auto split8 = [&](const float (&v)[8], u32x4 &hi, u32x4 &lo) {
-        uint32_t hh[4], mm[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2 p = {v[2 * j], v[2 * j + 1]};
-            const h16x2 ph = __builtin_convertvector(p, h16x2);
-            const f32x2 pb = __builtin_convertvector(ph, f32x2);
-            f32x2 q = {p.x - pb.x, p.y - pb.y};
-            const h16x2 pm = __builtin_convertvector(q, h16x2);
-            hh[j] = __builtin_bit_cast(uint32_t, ph);
-            mm[j] = __builtin_bit_cast(uint32_t, pm);
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2 p = {v[8 * f + 2 * j], v[8 * f + 2 * j + 1]};
+                const h16x2 ph = __builtin_convertvector(p, h16x2);
+                const f32x2 pb = __builtin_convertvector(ph, f32x2);
+                f32x2 q = {p.x - pb.x, p.y - pb.y};
+                const h16x2 pm = __builtin_convertvector(q, h16x2);
+                hh[f][j] = __builtin_bit_cast(uint32_t, ph);
+                mm[f][j] = __builtin_bit_cast(uint32_t, pm);
+            }
+        unsigned char *mine = buf + (loads_g * 8 + 2 * cg) * (2 * kFragBytes);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            *(u32x4 *)(mine + ((f * 2 + 0) * 64 + lane) * 16) = u32x4{hh[f][0], hh[f][1], hh[f][2], hh[f][3]};
+            *(u32x4 *)(mine + ((f * 2 + 1) * 64 + lane) * 16) = u32x4{mm[f][0], mm[f][1], mm[f][2], mm[f][3]};
         }
-        hi = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        lo = u32x4{mm[0], mm[1], mm[2], mm[3]};
     };
 
-    if (s0 < s1) fetch(s0, av[0], gv[0]);
-    for (int64_t s = s0; s < s1; ++s) {
-        const int cur = (int)((s - s0) & 1);
-        u32x4 Ah, Am, Gh, Gm;
-        if (cur == 0) {
-            split8(av[0], Ah, Am);
-            split8(gv[0], Gh, Gm);
-            if (s + 1 < s1) fetch(s + 1, av[1], gv[1]);
-        } else {
-            split8(av[1], Ah, Am);
-            split8(gv[1], Gh, Gm);
-            if (s + 1 < s1) fetch(s + 1, av[0], gv[0]);
-        }
-        unsigned char *buf = lds + cur * (8 * 2 * kFragBytes);
-        *(u32x4 *)(buf + ((wave * 2 + 0) * 64 + lane) * 16) = Gh;
-        *(u32x4 *)(buf + ((wave * 2 + 1) * 64 + lane) * 16) = Gm;
-        __syncthreads();
 #pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            const u32x4 Bh = *(const u32x4 *)(buf + ((jb * 2 + 0) * 64 + lane) * 16);
-            const u32x4 Bm = *(const u32x4 *)(buf + ((jb * 2 + 1) * 64 + lane) * 16);
-            f32x16 t = acc[jb];
-            t = mfma_h(Am, Bh, t);
-            t = mfma_h(Ah, Bm, t);
-            t = mfma_h(Ah, Bh, t);
-            acc[jb] = t;
+    for (int d = 0; d < kAtgDepth; ++d)
+        if (s0 + d < s1) fetch(s0 + d, ring[d]);
+    for (int64_t base = s0; base < s1; base += kAtgDepth) {
+#pragma unroll
+        for (int d = 0; d < kAtgDepth; ++d) {
+            const int64_t s = base + d;
+            if (s < s1) {                                        // (uniform over the workgroup)
+                unsigned char *buf = lds + (int)((s - s0) & 1) * (2 * 8 * 2 * kFragBytes);
+                publish(s, ring[d], buf);
+                if (s + kAtgDepth < s1) fetch(s + kAtgDepth, ring[d]);
+                __syncthreads();
+                u32x4 Af[2][2];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp)
+                        Af[ib][sp] = *(const u32x4 *)(buf + (((2 * iw + ib) * 2 + sp) * 64 + lane) * 16);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const unsigned char *gb = buf + ((8 + 4 * jh + jb) * 2) * kFragBytes;
+                    const u32x4 Bh = *(const u32x4 *)(gb + (0 * 64 + lane) * 16);
+                    const u32x4 Bm = *(const u32x4 *)(gb + (1 * 64 + lane) * 16);
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        f32x16 t = acc[ib][jb];
+                        t = mfma_h(Af[ib][1], Bh, t);
+                        t = mfma_h(Af[ib][0], Bm, t);
+                        t = mfma_h(Af[ib][0], Bh, t);
+                        acc[ib][jb] = t;
+                    }
+                }
+            }
         }
     }
-    // D[i][j]: i = 32*wave + (reg&3) + 8*(reg>>2) + 4*h, j = 32*jb + c
+    // D[i][j]: i = 64*iw + 32*ib + (reg&3) + 8*(reg>>2) + 4*(lane>>5), j = 128*jh + 32*jb + (lane&31)
     float *out = partial + (size_t)blockIdx.x * (kK * kN);
+    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+    for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int i = 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            out[i * kN + 32 * jb + c] = acc[jb][reg] * back_a * back_b;
-        }
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = 64 * iw + 32 * ib + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                out[i * kN + 128 * jh + 32 * jb + c] = acc[ib][jb][reg] * back_a * back_b;
+            }
 }
 
 __global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict__ partial, int n_wg,
@@ -844,8 +876,8 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)kN * 4, kK, s);
         return e == hipSuccess ? 0 : gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32: memset");
     }
-    if (A == nullptr || G == nullptr || a_absmax_bound == nullptr || g_absmax_bound == nullptr ||
-        workspace == nullptr)
+    if (A == nullptr || G == nullptr || rows_a == nullptr || rows_g == nullptr ||
+        a_absmax_bound == nullptr || g_absmax_bound == nullptr || workspace == nullptr)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL pointer");
     if (workspace_bytes < gcn_gemm_atg256_workspace_bytes(n_list))
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_atg256_f32: workspace too small");

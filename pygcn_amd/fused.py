@@ -70,6 +70,7 @@ class RowSets:
         self.rows2 = torch.unique(graph.col[idx].to(torch.int64))                # sorted
         self.n2 = int(self.rows2.numel())
         self.rows2_i32 = self.rows2.to(torch.int32)
+        self.rows2_padded = _spmm.padded_row_list(self.rows2)     # (for the weight-gradient kernel)
         mask2 = torch.zeros(graph.shape[1], dtype=torch.bool, device=dev)
         mask2[self.rows2] = True
         self.hint2 = pack_row_flags(mask2)
@@ -181,8 +182,8 @@ class GCN2RowsFunction(torch.autograd.Function):
         fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
         gs2 = None
         if need_w2:
-            grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_i32, rs.rows2_i32, ctx.h_bound,
-                                             gs_bound) if fast else None
+            grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, rs.rows2_padded,
+                                             ctx.h_bound, gs_bound, n_list=rs.n2) if fast else None
             if grad_w2 is None:
                 gs2 = grad_sup2.index_select(0, rs.rows2)
                 grad_w2 = _weight_grad(h1c, gs2)
@@ -208,7 +209,8 @@ class GCN2RowsFunction(torch.autograd.Function):
                              out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
                 if f32 and _spmm._gemm_scheme == "h2" and x.shape[1] == 256 and gpre1.shape[1] == 256:
                     z_bound = graph.inf_norm() * _spmm.absmax_cached(x) * 1.0001
-                    grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_i32, None, z_bound, gpre_bound)
+                    grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, z_bound,
+                                                     gpre_bound, n_list=rs.n2)
                 if grad_w1 is None:
                     grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
         elif need_x or need_w1:

@@ -417,40 +417,77 @@ def gemm_bf16(X, W):
     return Y
 
 
-def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None):
+_identity_lists = {}
+
+
+def padded_row_list(rows):
+    """int32 copy of a row-index list, padded to a multiple of 16 entries by repeating its last
+    entry (what gcn_gemm_atg256_f32 expects: the 16 indices of a step are one scalar load)."""
+    r = rows.to(torch.int32)
+    pad = (-r.numel()) % 16
+    if pad and r.numel():
+        r = torch.cat([r, r[-1:].expand(pad)])
+    return r.contiguous()
+
+
+def _identity_list(n, device):
+    """0, 1, …, n-1 (padded) — cached per device, grown on demand."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    have = _identity_lists.get(key)
+    need = (n + 15) // 16 * 16
+    if have is None or have.numel() < need:
+        have = _identity_lists[key] = torch.arange(need, dtype=torch.int32, device=device).clamp_(max=max(n - 1, 0))
+        have._n = n
+    if getattr(have, "_n", None) != n:       # the clamp of the padding depends on n
+        have = torch.arange(need, dtype=torch.int32, device=device).clamp_(max=max(n - 1, 0))
+        have._n = n
+        _identity_lists[key] = have
+    return have
+
+
+def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None):
     """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] -> [256, 256] through the gather-fused MFMA kernel (C-ABI
     gcn_gemm_atg256_f32): the weight gradient `inputᵀ · grad_support` over a LIST of rows, without
     compacting either operand first.  rows_*: int32 device index lists or None (= all rows, in
-    order; both operands must then list the same number of rows).  *_bound: DEVICE float [1] upper
-    bounds of max|A|, max|G| (computed here by a reduction pass when missing).  None if the
-    operands do not fit the kernel (fp32, 256 columns each)."""
+    order).  A list may be longer than `n_list` (padding to a multiple of 16, padded_row_list());
+    unpadded lists are padded here.  *_bound: DEVICE float [1] upper bounds of max|A|, max|G|
+    (computed here by a reduction pass over the listed rows when missing).  None if the operands
+    do not fit the kernel (fp32, 256 columns each)."""
     if (A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda or A.dim() != 2
             or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
             or G.stride(1) != 1):
         return None
-    n_a = rows_a.numel() if rows_a is not None else A.shape[0]
-    n_g = rows_g.numel() if rows_g is not None else G.shape[0]
-    if n_a != n_g:
-        raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
-    for r in (rows_a, rows_g):
-        if r is not None and (r.dtype != torch.int32 or not r.is_contiguous() or r.device != A.device):
+    if n_list is None:
+        n_a = rows_a.numel() if rows_a is not None else A.shape[0]
+        n_g = rows_g.numel() if rows_g is not None else G.shape[0]
+        if n_a != n_g:
+            raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
+        n_list = n_a
+    lists = []
+    for r, t in ((rows_a, A), (rows_g, G)):
+        if r is None:
+            if t.shape[0] < n_list:
+                raise RuntimeError("weight_grad_rows: operand has fewer rows than n_list")
+            r = _identity_list(n_list, A.device)
+        elif r.dtype != torch.int32 or not r.is_contiguous() or r.device != A.device:
             raise RuntimeError("weight_grad_rows: row lists must be contiguous int32 device tensors")
+        elif r.numel() < (n_list + 15) // 16 * 16:
+            r = padded_row_list(r[:n_list])
+        lists.append(r)
     # (no bound supplied: a reduction pass — over the LISTED rows only, the others may hold anything)
     if a_bound is None:
-        src = A.detach() if rows_a is None else A.detach().index_select(0, rows_a.long())
+        src = A.detach()[:n_list] if rows_a is None else A.detach().index_select(0, rows_a[:n_list].long())
         a_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
     if g_bound is None:
-        src = G.detach() if rows_g is None else G.detach().index_select(0, rows_g.long())
+        src = G.detach()[:n_list] if rows_g is None else G.detach().index_select(0, rows_g[:n_list].long())
         g_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
     L = _native.lib()
     out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
-    ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_a)
+    ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_list)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     with torch.cuda.device(A.device):
-        rc = L.gcn_gemm_atg256_f32(A.data_ptr(), A.stride(0),
-                                   rows_a.data_ptr() if rows_a is not None else None,
-                                   G.data_ptr(), G.stride(0),
-                                   rows_g.data_ptr() if rows_g is not None else None, n_a,
+        rc = L.gcn_gemm_atg256_f32(A.data_ptr(), A.stride(0), lists[0].data_ptr(),
+                                   G.data_ptr(), G.stride(0), lists[1].data_ptr(), n_list,
                                    a_bound.data_ptr(), g_bound.data_ptr(), out.data_ptr(), out.stride(0),
                                    ws.data_ptr(), ws_bytes, torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_gemm_atg256_f32")

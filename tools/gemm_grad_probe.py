@@ -16,13 +16,13 @@ N, n2 = 10_000_000, 1_620_000
 A = torch.randn(N, 256, device=dev); G = torch.randn(N, 256, device=dev) * 0.01
 W = torch.randn(256, 256, device=dev)
 rows = torch.sort(torch.randperm(N, device=dev)[:n2]).values
-r32 = rows.to(torch.int32)
+r32 = rows.to(torch.int32); rpad = S.padded_row_list(rows)
 ab, gb = A.abs().max().reshape(1), G.abs().max().reshape(1)
 Ac, Gc = A[rows].contiguous(), G[rows].contiguous()
 for rnd in range(3):
     print("round %d | grad_W: kernel+lists %.2f  kernel compact %.2f  gathers+K-split bmm %.2f  (gathers alone %.2f)"
           " | grad_in: kernel+list %.2f  gather+kernel %.2f | dense 1e7 rows: kernel %.2f  K-split bmm %.2f" % (
-        rnd, t(lambda: S.weight_grad_rows(A, G, r32, r32, ab, gb)), t(lambda: S.weight_grad_rows(Ac, Gc, None, None, ab, gb)),
+        rnd, t(lambda: S.weight_grad_rows(A, G, rpad, rpad, ab, gb, n_list=n2)), t(lambda: S.weight_grad_rows(Ac, Gc, None, None, ab, gb)),
         t(lambda: (S.set_gemm_scheme("bf16x3"), S._weight_grad(A.index_select(0, rows), G.index_select(0, rows)), S.set_gemm_scheme("h2"))),
         t(lambda: (A.index_select(0, rows), G.index_select(0, rows))),
         t(lambda: S.gemm_xw256(G, W, gb, rows=r32)), t(lambda: S.gemm_xw256(G.index_select(0, rows), W, gb)),
