@@ -463,6 +463,8 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
         if n_a != n_g:
             raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
         n_list = n_a
+    if n_list == 0:
+        return torch.zeros((256, 256), dtype=torch.float32, device=A.device)
     lists = []
     for r, t in ((rows_a, A), (rows_g, G)):
         if r is None:
