@@ -251,6 +251,7 @@ def main():
 
     from pygcn_amd import GCN, CSRGraph, _native
     from pygcn_amd import spmm as spmm_mod
+    from pygcn_amd.functional import nll_loss      # (= F.nll_loss, mean reduction; gather / scatter)
     from pygcn_amd.utils import rmat_graph
     _native.lib()
 
@@ -321,7 +322,7 @@ def main():
             # upstream: F.nll_loss(output[idx_train], labels[idx_train]) (train.py:153) — the model is
             # told which rows the loss reads, so the backward pass runs on the rows that can be
             # non-zero (pygcn_amd/fused.py); the forward pass is the full one
-            loss = F.nll_loss(fwd_model(x, adj, rows=idx_train).float(), labels_train)
+            loss = nll_loss(fwd_model(x, adj, rows=idx_train).float(), labels_train)
         loss.backward()
         if world > 1:
             fwd_model.allreduce_grads()

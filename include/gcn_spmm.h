@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 17
+#define GCN_ABI_VERSION 18
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -326,12 +326,17 @@ int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw,
  * x_rows: optional DEVICE int32 list of M row indices — output row r is then the product of input
  * row x_rows[r] (the gradient GEMMs run on the rows that can be non-zero without a compacting
  * copy); NULL = rows 0 .. M-1.
+ * mask_src: optional DEVICE fp32 [*, 256] (leading dimension ld_mask): the store becomes
+ * y = mask_src[input row, col] > 0 ? y * mask_scale : 0 — the backward of the fused ReLU / dropout
+ * epilogue (out > 0 encodes ReLU and keep, scale = 1 / (1 - p)) applied to the grad_input GEMM in
+ * its own store; y_absmax then reports the maximum of the masked values.  NULL = plain product.
  * Workspace >= gcn_gemm_xw256_h2_workspace_bytes().  `torch.mm(input, weight)`, pygcn/layers.py:33.
  */
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);
 int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
                           int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
-                          float *y_absmax, void *workspace, size_t workspace_bytes, void *stream);
+                          float *y_absmax, const float *mask_src, int64_t ld_mask, float mask_scale,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Y[M, N] = X[M, K] · W[K, N] for bf16 storage (config C5: 128 -> 128): bf16 in / out, fp32

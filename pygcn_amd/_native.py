@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 17
+GCN_ABI_VERSION = 18
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -166,8 +166,8 @@ def lib():
     L.gcn_gemm_xw256_f32_h2.restype = ctypes.c_int
     L.gcn_gemm_xw256_f32_h2.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
-                                        ctypes.c_void_p]
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_bf16_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_bf16_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.gcn_gemm_xw_bf16.restype = ctypes.c_int

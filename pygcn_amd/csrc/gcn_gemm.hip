@@ -357,7 +357,8 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c)
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
     const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
-    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax)
+    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const float *__restrict__ mask_src,
+    int64_t ld_mask, float mask_scale)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -464,12 +465,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     float vmax = 0.f;
     if (row_ok) {
         float *yrow = Y + row * ldy + 4 * (lane >> 5);
+        // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
+        const float *mrow = mask_src ? mask_src + src_row * ld_mask + 4 * (lane >> 5) : nullptr;
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
                            acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
+                if (mrow != nullptr) {
+                    const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
+                    v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
+                    v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
+                    v.z = m.z > 0.f ? v.z * mask_scale : 0.f;
+                    v.w = m.w > 0.f ? v.w * mask_scale : 0.f;
+                }
                 *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
                 vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
@@ -779,7 +789,8 @@ size_t gcn_gemm_xw256_h2_workspace_bytes(void)
 
 int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
                           int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
-                          float *y_absmax, void *workspace, size_t workspace_bytes, void *stream)
+                          float *y_absmax, const float *mask_src, int64_t ld_mask, float mask_scale,
+                          void *workspace, size_t workspace_bytes, void *stream)
 {
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
@@ -789,14 +800,15 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     if (workspace_bytes < gcn_gemm_xw256_h2_workspace_bytes())
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw256_f32_h2: workspace too small");
     if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 4) != 0 ||
-        (ldy % 4) != 0 || (((uintptr_t)x_absmax_bound) | ((uintptr_t)y_absmax)) % 4 != 0)
+        (ldy % 4) != 0 || (((uintptr_t)x_absmax_bound) | ((uintptr_t)y_absmax)) % 4 != 0 ||
+        ((uintptr_t)mask_src) % 16 != 0 || (mask_src != nullptr && (ld_mask % 4 != 0 || ld_mask < kN)))
         return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32_h2: X / Y rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
     hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
                        x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                       (uint32_t *)y_absmax);
+                       (uint32_t *)y_absmax, mask_src, ld_mask, mask_scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
     return 0;

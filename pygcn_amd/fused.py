@@ -177,30 +177,33 @@ class GCN2RowsFunction(torch.autograd.Function):
         f32 = dt == torch.float32
         gs_bound = graph_t.inf_norm() * torch.linalg.vector_norm(gp, ord=float("inf")) * 1.0001 \
             if f32 else None
-        h1c = h1.index_select(0, rs.rows2)                  # [|R2|, H] (the ReLU / dropout mask)
-        # the GEMMs read the rows R2 of grad_sup2 / h1 in place (row lists), no compacting copies
+        # the GEMMs read the rows R2 of grad_sup2 / h1 in place (row lists), no compacting copies;
+        # the ReLU / dropout mask (h1 > 0 encodes ReLU and keep) is applied in the GEMM's store
         fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
-        gs2 = None
+        gs2 = h1c = None
         if need_w2:
             grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, rs.rows2_padded,
                                              ctx.h_bound, gs_bound, n_list=rs.n2) if fast else None
             if grad_w2 is None:
-                gs2 = grad_sup2.index_select(0, rs.rows2)
+                gs2, h1c = grad_sup2.index_select(0, rs.rows2), h1.index_select(0, rs.rows2)
                 grad_w2 = _weight_grad(h1c, gs2)
         gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
         w2t = w2.t().contiguous()
-        gh1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, rows=rs.rows2_i32) if fast else None
-        if gh1 is None:
+        gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, rows=rs.rows2_i32, mask_src=h1,
+                           mask_scale=ctx.scale) if fast else None
+        if gpre1 is None:
             gs2 = grad_sup2.index_select(0, rs.rows2) if gs2 is None else gs2
+            h1c = h1.index_select(0, rs.rows2) if h1c is None else h1c
             gh1 = _dense_forward(gs2, w2t, gs_bound, gh_max)
-        del gs2, grad_pre2, grad_sup2
-        # ---- ReLU / dropout mask on the compact rows (out > 0 encodes ReLU and keep)
-        gpre1 = torch.where(h1c > 0, gh1 * ctx.scale if ctx.scale != 1.0 else gh1,
-                            torch.zeros((), dtype=dt, device=dev))
-        del gh1, h1c
+            gpre1 = torch.where(h1c > 0, gh1 * ctx.scale if ctx.scale != 1.0 else gh1,
+                                torch.zeros((), dtype=dt, device=dev))
+            if gh_max is not None:
+                gh_max = gh_max * ctx.scale
+            del gh1
+        del gs2, h1c, grad_pre2, grad_sup2
         if ctx.has_bias[0] and need_b1:
             grad_b1 = gpre1.float().sum(0).to(ctx.bias_dtypes[0])
-        gpre_bound = gh_max * ctx.scale if f32 else None
+        gpre_bound = gh_max if f32 else None
         # ---- layer 1
         if not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
             if need_w1:

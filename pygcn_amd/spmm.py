@@ -336,7 +336,7 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
-def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None):
+def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -346,7 +346,9 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None):
     the caller has none, max|X| is computed here by one reduction pass.  `y_absmax` (DEVICE float
     tensor [1], zeroed by the caller) receives max|Y|, from which a layer derives the next bound
     without a pass over the data.  `rows` (int32 device list): output row r is the product of
-    input row rows[r] — a gather fused into the kernel's loads.
+    input row rows[r] — a gather fused into the kernel's loads.  `mask_src` ([*, 256] fp32, read
+    at the same input rows): the store becomes mask_src > 0 ? y * mask_scale : 0, the backward of a
+    fused ReLU / dropout epilogue, in the GEMM's own store (None if it cannot be fused).
     Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
     product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
     underflow — tests/test_gemm_gpu.py)."""
@@ -355,6 +357,11 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None):
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
+    if mask_src is not None and (_gemm_scheme != "h2" or mask_src.dtype != torch.float32
+                                 or mask_src.dim() != 2 or mask_src.shape[1] != 256
+                                 or mask_src.stride(1) != 1 or mask_src.stride(0) % 4
+                                 or mask_src.data_ptr() % 16 or mask_src.device != X.device):
+        return None
     if rows is not None:
         if _gemm_scheme != "h2":
             X, rows = X.index_select(0, rows.long()), None
@@ -381,7 +388,9 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None):
                                          W.data_ptr(), W.stride(0),
                                          Y.data_ptr(), Y.stride(0), m_out, x_bound.data_ptr(),
                                          y_absmax.data_ptr() if y_absmax is not None else None,
-                                         ws.data_ptr(), ws_bytes, stream)
+                                         mask_src.data_ptr() if mask_src is not None else None,
+                                         mask_src.stride(0) if mask_src is not None else 0,
+                                         float(mask_scale), ws.data_ptr(), ws_bytes, stream)
             _native.check(rc, "gcn_gemm_xw256_f32_h2")
             return Y
         ws_bytes = L.gcn_gemm_xw256_workspace_bytes()

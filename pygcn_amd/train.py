@@ -14,7 +14,8 @@ import time
 
 import numpy as np
 import torch
-from torch.nn.functional import nll_loss
+
+from functional import nll_loss      # F.nll_loss(mean) of train.py:153 as a gather / scatter pair
 
 from models import GCN
 from utils import DEFAULT_CORA, accuracy, load_data

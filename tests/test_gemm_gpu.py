@@ -247,3 +247,22 @@ def test_bf16_gemm_matches_fp32_on_rounded_inputs(dev, K, N, M):
     refs = wide[:, K:].double() @ W.double()
     assert bool(((Ys.double() - refs).abs() <= 2.0 ** -8 * refs.abs() + 1e-5 * float(refs.abs().max())).all())
     assert gemm_bf16(X[:, :64], W[:64]) is None and gemm_bf16(X.float(), W.float()) is None
+
+
+def test_gemm_with_fused_relu_dropout_mask(dev):
+    """mask_src: y = mask_src[input row] > 0 ? y * scale : 0 in the GEMM's own store (the backward
+    of the fused ReLU / dropout epilogue on the grad_input GEMM), with and without a row list."""
+    from pygcn_amd.spmm import gemm_xw256
+    gen = torch.Generator(device=dev).manual_seed(4)
+    X = torch.randn(4000, 256, generator=gen, device=dev)
+    H = torch.randn(4000, 256, generator=gen, device=dev).clamp_min(0) * (torch.rand(4000, 256, generator=gen, device=dev) > 0.5)
+    W = torch.randn(256, 256, generator=gen, device=dev)
+    b = X.abs().max().reshape(1)
+    plain = gemm_xw256(X, W, x_bound=b)
+    ymax = torch.zeros(1, device=dev)
+    got = gemm_xw256(X, W, x_bound=b, y_absmax=ymax, mask_src=H, mask_scale=2.0)
+    want = torch.where(H > 0, plain * 2.0, torch.zeros_like(plain))
+    assert torch.equal(got, want) and float(ymax) == float(want.abs().max())
+    rows = torch.randperm(4000, device=dev)[:999].to(torch.int32)
+    got_r = gemm_xw256(X, W, x_bound=b, rows=rows, mask_src=H, mask_scale=2.0)
+    assert torch.equal(got_r, want[rows.long()])
