@@ -275,6 +275,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_kernel(const float *__
 // subnormal): the absolute error per element is bounded by 2^-38 · max|X|; inputs with a wider
 // dynamic range that matters should use the 3 x bf16 entry point.  Optionally the kernel reports
 // max|Y| (one atomic max per wave) — the next layer's bound.
+#ifndef GEMM_H2_RING
+#define GEMM_H2_RING 4
+#endif
+#ifndef GEMM_H2_GRID
+#define GEMM_H2_GRID 256          /* persistent workgroups: one per CU */
+#endif
+constexpr int kH2Ring = GEMM_H2_RING;                      // X ring: steps in flight + 1
 constexpr int kH2ChunkBytes = 2 * 8 * kFragBytes;          // 2 splits x 8 column blocks = 16 KiB
 constexpr int kH2StageBytes = kStage * kH2ChunkBytes;
 constexpr int kH2WLoads = kH2StageBytes / 16 / kThreads;
@@ -360,14 +367,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const float *__restrict__ mask_src,
     int64_t ld_mask, float mask_scale)
 {
+    // PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, … and the software
+    // pipeline runs ACROSS tile boundaries — the X fragments of the next tile's first steps and
+    // its first W stage are already in flight while the current tile's last steps are multiplied
+    // and its 128 accumulator registers are stored, so no tile pays a cold prologue (with one
+    // workgroup per CU nothing else would cover it).  The X ring has kH2Ring slots with static
+    // indices; kChunks % kH2Ring == 0 keeps slot = step % kH2Ring valid across the boundary.
+    static_assert(kChunks % kH2Ring == 0, "the X ring must divide the K steps of a tile");
+    static_assert(kChunks % kStage == 0 && (kChunks / kStage) % 2 == 0, "W stages must alternate evenly");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t row = (int64_t)blockIdx.x * kTileRows + 32 * wave + (lane & 31);
-    const bool row_ok = row < M;
-    // optional gather: output row `row` is the product of input row x_rows[row]
-    const int64_t src_row = row_ok ? (x_rows ? (int64_t)x_rows[row] : row) : 0;
-    const float *xrow = X + src_row * ldx + 8 * (lane >> 5);
     const unsigned char *wimg = ws + kH2HeaderBytes;
+    const int64_t n_tiles = (M + kTileRows - 1) / kTileRows;
 
     // scales (wave-uniform scalars)
     int x_exp = 14 - floor_log2f(*x_bound);
@@ -380,15 +391,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
     const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);   // exact steps
 
-    f32x16 acc[8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-
     u32x4 wreg[kH2WLoads];
+    const unsigned char *wl = wimg;     // (re-made opaque per tile, see the tile loop)
     auto w_load = [&](int st) {
-        const u32x4 *src = (const u32x4 *)(wimg + (size_t)st * kH2StageBytes);
+        const u32x4 *src = (const u32x4 *)(wl + (size_t)st * kH2StageBytes);
 #pragma unroll
         for (int i = 0; i < kH2WLoads; ++i) wreg[i] = src[i * kThreads + tid];
     };
@@ -397,19 +403,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
         for (int i = 0; i < kH2WLoads; ++i) dst[i * kThreads + tid] = wreg[i];
     };
-    f32x4 ar[3][2];
-    auto a_fetch = [&](int c, f32x4 &lo, f32x4 &hi) {
-        const f32x4 *p = (const f32x4 *)(xrow + c * kChunk);
+    f32x4 ar[kH2Ring][2];      // X fragments: this step + (kH2Ring - 1) steps of prefetch
+    auto a_fetch = [&](const float *xr, int c, f32x4 &lo, f32x4 &hi) {
+        const f32x4 *p = (const f32x4 *)(xr + c * kChunk);
         lo = p[0];
         hi = p[1];
     };
     u32x4 Ah, Am;
-    auto split_frag = [&](const f32x4 &lo, const f32x4 &hi) {
+    auto split_frag = [&](const f32x4 &lo, const f32x4 &hi, bool ok) {
         const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         uint32_t h[4], m[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float x0 = row_ok ? av[2 * j] * xs : 0.f, x1 = row_ok ? av[2 * j + 1] * xs : 0.f;
+            const float x0 = ok ? av[2 * j] * xs : 0.f, x1 = ok ? av[2 * j + 1] * xs : 0.f;
             f32x2 v = {x0, x1};
             const h16x2 hh = __builtin_convertvector(v, h16x2);
             const f32x2 hb = __builtin_convertvector(hh, f32x2);
@@ -421,69 +427,120 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         Ah = u32x4{h[0], h[1], h[2], h[3]};
         Am = u32x4{m[0], m[1], m[2], m[3]};
     };
+    // (row of this lane in tile t, is it inside the matrix, the input row it reads)
+    auto tile_rows = [&](int64_t t, int64_t &row, bool &ok, int64_t &src) {
+        row = t * kTileRows + 32 * wave + (lane & 31);
+        ok = t < n_tiles && row < M;
+        // optional gather: output row `row` is the product of input row x_rows[row]
+        src = ok ? (x_rows ? (int64_t)x_rows[row] : row) : 0;
+    };
 
+    int64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    int64_t row, src_row;
+    bool row_ok;
+    tile_rows(tile, row, row_ok, src_row);
+    const float *xrow = X + src_row * ldx + 8 * (lane >> 5);
     w_load(0);
-    a_fetch(0, ar[0][0], ar[0][1]);
-    a_fetch(1, ar[1][0], ar[1][1]);
+#pragma unroll
+    for (int c = 0; c < kH2Ring - 1; ++c) a_fetch(xrow, c, ar[c][0], ar[c][1]);
     w_store(0);
-    split_frag(ar[0][0], ar[0][1]);
-#pragma unroll
-    for (int c = 0; c < kChunks; ++c) {
-        const int st = c / kStage;
-        if (c % kStage == 0) {
-            __syncthreads();
-            if ((st + 1) * kStage < kChunks) w_load(st + 1);
-        }
-        if (c + 2 < kChunks) a_fetch(c + 2, ar[(c + 2) % 3][0], ar[(c + 2) % 3][1]);
-        const u32x4 Xh = Ah, Xm = Am;
-        const unsigned char *buf = lds + (st & 1) * kH2StageBytes + (c % kStage) * kH2ChunkBytes;
-        u32x4 Bf[2][2];
-        auto b_read = [&](int nb, u32x4 (&dst)[2]) {
-            dst[0] = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
-            dst[1] = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
-        };
-        b_read(0, Bf[0]);
-#pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
-            if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
-            const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
-            f32x16 t = acc[nb];
-            __builtin_amdgcn_s_setprio(1);
-            t = mfma_h(Bm, Xh, t);       // smaller terms first
-            t = mfma_h(Bh, Xm, t);
-            t = mfma_h(Bh, Xh, t);
-            __builtin_amdgcn_s_setprio(0);
-            acc[nb] = t;
-        }
-        if (c % kStage == kStage - 1 && c + 1 < kChunks) w_store((st + 1) & 1);
-        if (c + 1 < kChunks) {
-            split_frag(ar[(c + 1) % 3][0], ar[(c + 1) % 3][1]);
-            asm volatile("" : "+v"(Ah), "+v"(Am));
-        }
-    }
-
+    split_frag(ar[0][0], ar[0][1], row_ok);
     float vmax = 0.f;
-    if (row_ok) {
-        float *yrow = Y + row * ldy + 4 * (lane >> 5);
-        // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
-        const float *mrow = mask_src ? mask_src + src_row * ld_mask + 4 * (lane >> 5) : nullptr;
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const bool has_next = tile + gridDim.x < n_tiles;      // (uniform over the workgroup)
+        // the W image's 32 load addresses are loop-invariant; left visible, hipcc hoists all of
+        // them out of the tile loop as 64-bit VGPR pairs and spills 50 registers
+        asm volatile("" : "+s"(wl));
+        int64_t row_n, src_n;
+        bool ok_n;
+        tile_rows(tile + gridDim.x, row_n, ok_n, src_n);
+        const float *xrow_n = X + src_n * ldx + 8 * (lane >> 5);
+        f32x16 acc[8];
 #pragma unroll
-        for (int nb = 0; nb < 8; ++nb) {
+        for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
-                           acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
-                if (mrow != nullptr) {
-                    const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
-                    v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
-                    v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
-                    v.z = m.z > 0.f ? v.z * mask_scale : 0.f;
-                    v.w = m.w > 0.f ? v.w * mask_scale : 0.f;
-                }
-                *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
-                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int st = c / kStage;
+            if (c % kStage == 0) {
+                __syncthreads();
+                if ((st + 1) * kStage < kChunks)
+                    w_load(st + 1);
+                else if (has_next)
+                    w_load(0);                                    // the next tile's first stage
+            }
+            {
+                constexpr int R = kH2Ring;
+                const int fc = c + R - 1;                         // step fetched now
+                if (fc < kChunks)
+                    a_fetch(xrow, fc, ar[fc % R][0], ar[fc % R][1]);
+                else if (has_next)
+                    a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
+            }
+            const u32x4 Xh = Ah, Xm = Am;
+            const unsigned char *buf = lds + (st & 1) * kH2StageBytes + (c % kStage) * kH2ChunkBytes;
+            u32x4 Bf[2][2];
+            auto b_read = [&](int nb, u32x4 (&dst)[2]) {
+                dst[0] = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
+                dst[1] = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
+            };
+            b_read(0, Bf[0]);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
+                const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
+                f32x16 t = acc[nb];
+                __builtin_amdgcn_s_setprio(1);
+                t = mfma_h(Bm, Xh, t);       // smaller terms first
+                t = mfma_h(Bh, Xm, t);
+                t = mfma_h(Bh, Xh, t);
+                __builtin_amdgcn_s_setprio(0);
+                acc[nb] = t;
+            }
+            if (c % kStage == kStage - 1) {
+                if (c + 1 < kChunks)
+                    w_store((st + 1) & 1);
+                else if (has_next)
+                    w_store(0);              // (stage kChunks/kStage would use buffer 0 too)
+            }
+            if (c + 1 < kChunks) {
+                split_frag(ar[(c + 1) % kH2Ring][0], ar[(c + 1) % kH2Ring][1], row_ok);
+                asm volatile("" : "+v"(Ah), "+v"(Am));
+            } else if (has_next) {
+                split_frag(ar[0][0], ar[0][1], ok_n);
+                asm volatile("" : "+v"(Ah), "+v"(Am));
             }
         }
+
+        if (row_ok) {
+            float *yrow = Y + row * ldy + 4 * (lane >> 5);
+            // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
+            const float *mrow = mask_src ? mask_src + src_row * ld_mask + 4 * (lane >> 5) : nullptr;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
+                               acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
+                    if (mrow != nullptr) {
+                        const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
+                        v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
+                        v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
+                        v.z = m.z > 0.f ? v.z * mask_scale : 0.f;
+                        v.w = m.w > 0.f ? v.w * mask_scale : 0.f;
+                    }
+                    *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
+            }
+        }
+        row = row_n;
+        row_ok = ok_n;
+        src_row = src_n;
+        xrow = xrow_n;
     }
     if (y_absmax != nullptr) {                 // |y| >= 0: float order == unsigned order of the bits
 #pragma unroll
@@ -491,7 +548,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         if (lane == 0 && vmax > 0.f) atomicMax(y_absmax, __float_as_uint(vmax));
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // bf16 storage (config C5): Y[M,N] = X[M,K] · W[K,N], bf16 in / out, fp32 accumulate, (K, N) in
@@ -806,7 +862,8 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
-    hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
+    hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx,
                        x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                        (uint32_t *)y_absmax, mask_src, ld_mask, mask_scale);
     hipError_t e = hipGetLastError();
