@@ -545,11 +545,13 @@ K_SPLIT = 128          # slabs of the weight-gradient reduction
 MIN_ROWS = 1 << 17     # below this the plain GEMMs are launch-bound anyway
 
 
-def _weight_grad(input, grad):
-    """inputᵀ · grad: the hand-written MFMA kernel for 256-wide fp32 layers, otherwise hipBLASLt
-    with the reduction over the graph's vertices cut into K_SPLIT slabs."""
-    if input.shape[0] >= 4096 and _gemm_scheme == "h2":
-        out = weight_grad_rows(input, grad)
+def _weight_grad(input, grad, a_bound=None, g_bound=None):
+    """inputᵀ · grad: the hand-written MFMA kernel for 256-wide fp32 layers when the caller knows
+    bounds of both operands' maxima (the kernel's scaling needs them; two reduction passes over
+    [N, 256] tensors would cost what the kernel saves), otherwise hipBLASLt with the reduction
+    over the graph's vertices cut into K_SPLIT slabs."""
+    if a_bound is not None and g_bound is not None and _gemm_scheme == "h2":
+        out = weight_grad_rows(input, grad, a_bound=a_bound, g_bound=g_bound)
         if out is not None:
             return out
     n, b = input.shape[0], K_SPLIT
@@ -667,7 +669,11 @@ class GraphConvFunction(torch.autograd.Function):
         ctx.relu = bool(relu)
         ctx.log_softmax = bool(log_softmax)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
-        support = _dense_forward(input, weight)
+        # (a layer input that needs no gradient is the constant feature matrix: its maximum is
+        #  computed once and reused as the scaled GEMM's bound)
+        x_bound = absmax_cached(input) if (input.dtype == torch.float32 and not input.requires_grad
+                                           and input.is_cuda) else None
+        support = _dense_forward(input, weight, x_bound)
         out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
                        log_softmax=log_softmax)
         if relu or log_softmax:
