@@ -480,7 +480,7 @@ def main():
                                    f"{feat}->{feat}->{feat}, fwd+bwd+Adam, dropout {args.dropout}, NLL on the "
                                    f"first 140/2708 of the vertices (upstream idx_train share)",
                        "nodes": n_total, "nnz": nnz_total, "feat_dim": feat,
-                       "parallelism": (f"row-block x{world} (the fixed C4 graph cut into "
+                       "parallelism": (f"row-block x{world} (the fixed {args.config} graph cut into "
                                        f"nnz-balanced row blocks, built shard-locally), "
                                        f"{args.exchange} exchange"
                                        + (", pipelined by source block (own rows | halo rows)"

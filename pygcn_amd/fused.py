@@ -129,7 +129,8 @@ class GCN2RowsFunction(torch.autograd.Function):
         # X is constant (cached), and |relu/dropout(Â·S + b)| <= (‖Â‖∞·max|S| + max|b|) / (1 - p)
         bounded = x.dtype == torch.float32
         s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
-        sup1 = _dense_forward(x, w1, _spmm.absmax_cached(x) if bounded else None, s_max)
+        ctx.x_bound = _spmm.absmax_cached(x) if bounded else None
+        sup1 = _dense_forward(x, w1, ctx.x_bound, s_max)
         h1 = spmm_csr(graph, sup1, bias=b1, relu=True, dropout_p=dropout_p, seed=seed)
         del sup1
         h_bound = None
@@ -156,15 +157,22 @@ class GCN2RowsFunction(torch.autograd.Function):
         need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad[:5]
         n, dev, dt = graph.shape[0], x.device, h1.dtype
         graph_t = graph.t()
-        # ---- loss rows: log_softmax backward on [|R|, C]
-        g = grad_rows.float()
-        gp = g - out_rows.float().exp() * g.sum(1, keepdim=True)
+        # ---- loss rows: log_softmax backward on the compact [|R|, C] tensors — one HIP pass
+        # (gcn_log_softmax_backward_colsum: grad_pre and the bias gradient's column sums together)
+        one_pass = _spmm.backward_with_colsum(grad_rows.contiguous(), out_rows, log_softmax=True) \
+            if (grad_rows.dtype == out_rows.dtype and not rs.has_duplicates) else None
+        if one_pass is not None:
+            gp, colsum, _ = one_pass
+            grad_b2 = colsum.to(ctx.bias_dtypes[1]) if (ctx.has_bias[1] and need_b2) else None
+        else:                                              # (class counts the kernel does not take)
+            g = grad_rows.float()
+            gp = g - out_rows.float().exp() * g.sum(1, keepdim=True)
+            grad_b2 = gp.sum(0).to(ctx.bias_dtypes[1]) if (ctx.has_bias[1] and need_b2) else None
         dst_rows = rs.rows_user                            # where the rows of gp belong in [N, C]
         if rs.has_duplicates:                              # the same vertex listed twice: add up
             gp = torch.zeros((rs.n_u, gp.shape[1]), dtype=gp.dtype, device=dev).index_add_(
                 0, rs.inverse, gp)
             dst_rows = rs.rows_u
-        grad_b2 = gp.sum(0).to(ctx.bias_dtypes[1]) if (ctx.has_bias[1] and need_b2) else None
         gp = gp.to(dt)
         grad_w1 = grad_w2 = grad_b1 = grad_x = None
         if not (need_x or need_w1 or need_b1 or need_w2):
@@ -211,7 +219,7 @@ class GCN2RowsFunction(torch.autograd.Function):
                 z = spmm_csr(graph, x, tag="bwd", c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
                 if f32 and _spmm._gemm_scheme == "h2" and x.shape[1] == 256 and gpre1.shape[1] == 256:
-                    z_bound = graph.inf_norm() * _spmm.absmax_cached(x) * 1.0001
+                    z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
                     grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, z_bound,
                                                      gpre_bound, n_list=rs.n2)
                 if grad_w1 is None:

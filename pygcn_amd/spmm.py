@@ -521,13 +521,17 @@ _absmax_cache = {}
 
 
 def absmax_cached(t):
-    """max|t| as a DEVICE float tensor [1], computed once per (storage, version): for operands that
-    stay constant across steps (the feature matrix)."""
-    key = (t.data_ptr(), t.numel(), t._version)
-    hit = _absmax_cache.get(t.device.index)
-    if hit is None or hit[0] != key:
-        hit = _absmax_cache[t.device.index] = (key, t.detach().abs().max().float().reshape(1))
-    return hit[1]
+    """max|t| as a DEVICE float tensor [1], computed once per (tensor object, version): for operands
+    that stay constant across steps (the feature matrix).  The cache holds a weak reference to the
+    tensor OBJECT — a new tensor that happens to reuse the storage address of a freed one can
+    never inherit its bound (a bound that is too small would overflow the fp16 parts)."""
+    import weakref
+    key = t.device.index if t.device.index is not None else -1
+    hit = _absmax_cache.get(key)
+    if hit is None or hit[0]() is not t or hit[1] != t._version:
+        val = torch.linalg.vector_norm(t.detach(), ord=float("inf")).float().reshape(1)
+        hit = _absmax_cache[key] = (weakref.ref(t), t._version, val)
+    return hit[2]
 
 
 def _dense_forward(input, weight, x_bound=None, y_absmax=None):
