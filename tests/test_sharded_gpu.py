@@ -92,7 +92,8 @@ def _nccl_worker(rank, world, port, n, n_edges, out_dir):
     """The sharded path on the REAL backend (RCCL), world size 1 — the only RCCL execution a
     one-GPU box allows: communicator init bound to the device, all_gather_into_tensor (degree
     counts, halo count matrix, row all-gather), all_reduce (loss count, gradient bucket), barrier,
-    and the zero-peer point-to-point rounds, end to end against the plain single-GPU model."""
+    the zero-peer point-to-point rounds, and grouped isend / irecv to the rank itself through
+    `_p2p_begin` / `_p2p_end`, end to end against the plain single-GPU model."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
@@ -137,6 +138,22 @@ def _nccl_worker(rank, world, port, n, n_edges, out_dir):
             for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
                 e = (p.grad - q.grad).abs().max().item()
                 assert e <= 2e-5 * q.grad.abs().max().item(), (exchange, k, e)
+        # RCCL point-to-point through the path's own grouped-transfer helpers: at world size 1 the
+        # only peer is the rank itself, which RCCL accepts — two messages to the same peer in one
+        # group (the layout of the row-sparse gradient exchange), a zero-length one skipped on both
+        # sides, and a product launched between post and wait (the pipelined exchange)
+        from pygcn_amd import spmm_csr
+        from pygcn_amd.sharded import _p2p_begin, _p2p_end
+        pos = torch.arange(77, device=dev, dtype=torch.int32)
+        rows_out = torch.randn(5000, F, device=dev)
+        empty = torch.empty((0, F), device=dev)
+        got_pos, got_rows = torch.empty_like(pos), torch.empty_like(rows_out)
+        pending = _p2p_begin([(pos, 0), (rows_out, 0), (empty, 0)],
+                             [(got_pos, 0), (got_rows, 0), (torch.empty_like(empty), 0)], None)
+        overlapped = spmm_csr(g, x)                       # runs while the transfers are in flight
+        _p2p_end(pending)
+        assert torch.equal(got_pos, pos) and torch.equal(got_rows, rows_out)
+        assert torch.equal(overlapped, spmm_csr(g, x))
         open(os.path.join(out_dir, "ok_nccl"), "w").write("ok")
     finally:
         dist.destroy_process_group()
