@@ -22,15 +22,28 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """One hipcc process per source file (in parallel), then one link."""
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
-           "-I", os.path.join(ROOT, "include"), "-o", OUT + ".tmp"] + SRCS
-    cmd[1:1] = os.environ.get("PYGCN_HIPCC_FLAGS", "").split()    # tuning experiments only
+    flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-I", os.path.join(ROOT, "include")]
+    flags[0:0] = os.environ.get("PYGCN_HIPCC_FLAGS", "").split()    # tuning experiments only
+    objdir = os.path.join(HERE, "csrc", "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SRCS:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((obj, cmd, subprocess.Popen(cmd)))
+    for obj, cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", OUT + ".tmp"] + [j[0] for j in jobs]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
     os.replace(OUT + ".tmp", OUT)
     return OUT
 
