@@ -1103,3 +1103,36 @@ def test_unwritten_rows_are_never_read(dev, fout, share):
     for a_, b_ in zip(got, ref):
         assert bool(a_.isfinite().all())
         assert_normwise(a_.cpu(), b_.cpu().numpy(), TOL, "skip-write path vs plain path")
+
+
+def test_colsum_pass_refuses_row_bitmap_for_rows_wider_than_a_wavefront(dev):
+    """with F / lane width > 64 a row spans several wavefronts, so the one-pass backward
+    cannot produce the row bitmap — the C-ABI must say so (GCN_E_BADARG), never return success with
+    the bitmap and the count left unwritten."""
+    import ctypes
+    from pygcn_amd import _native
+    L = _native.lib()
+    n, F = 300, 512                                   # fp32: F / 4 = 128 lanes per row
+    g = torch.randn(n, F, device=dev)
+    o = torch.randn(n, F, device=dev)
+    res = torch.empty_like(g)
+    colsum = torch.empty(F, device=dev)
+    bits = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device=dev)
+    cnt = torch.full((1,), -7, dtype=torch.int32, device=dev)
+    ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F, _native.GCN_DTYPE_F32)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = L.gcn_relu_dropout_backward_colsum(_native.GCN_DTYPE_F32, g.data_ptr(), o.data_ptr(),
+                                            res.data_ptr(), colsum.data_ptr(), n, F, 1.0,
+                                            bits.data_ptr(), cnt.data_ptr(), 0, ws.data_ptr(),
+                                            ws_bytes, stream)
+    assert rc == -1 and b"lane width <= 64" in L.gcn_last_error()
+    torch.cuda.synchronize()
+    assert int(cnt) == -7 and bool((bits == -1).all())          # untouched, and the caller was told
+    # without the optional outputs the same shape is fine
+    rc = L.gcn_relu_dropout_backward_colsum(_native.GCN_DTYPE_F32, g.data_ptr(), o.data_ptr(),
+                                            res.data_ptr(), colsum.data_ptr(), n, F, 1.0, None, None,
+                                            0, ws.data_ptr(), ws_bytes, stream)
+    assert rc == 0
+    want = torch.where(o > 0, g, torch.zeros_like(g))
+    assert torch.equal(res, want) and torch.allclose(colsum, want.sum(0), rtol=1e-5, atol=1e-5)
