@@ -390,6 +390,7 @@ def main():
     if world > 1:   # launch window = exchange + local SpMM (the exchange step is part of it)
         for tag, a, b, _ in records:
             local_ms["fwd" if tag.startswith("fwd") else "bwd"] += a.elapsed_time(b)
+        wait_ms = [a.elapsed_time(b) for tag, a, b in adj.timing if tag == "fwd_wait"]
         records = [(tag, a, b, None) for tag, a, b in adj.timing]
         adj.timing = None
     fwd_ms = [a.elapsed_time(b) for tag, a, b, _ in records if tag == "fwd"]
@@ -539,6 +540,10 @@ def main():
             line["exchange_bytes_received_per_rank_max"] = {"fwd_dense": recv_max[0],
                                                             "bwd_sparse": recv_max[1]}
             line["setup_peak_bytes_per_rank_max"] = peak_setup
+            line["exchange_exposed_wait_ms_rank0"] = round(float(np.mean(wait_ms)), 4) if wait_ms else None
+            line["exchange_exposed_wait_note"] = ("time the compute stream waits for the halo rows "
+                                                  "AFTER the own-rows product has run under the "
+                                                  "transfers (pipelined dense exchange, rank 0)")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, feat,

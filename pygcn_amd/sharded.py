@@ -495,7 +495,9 @@ class ShardedGraph:
                 a_own, a_halo = self.split_block(transpose)
                 halo, pending = h.exchange_begin(local)
                 part = self._spmm(a_own, local, tag=tag)          # overlaps the transfers
+                ev_w = self._tic(local)                           # (diagnostic: exposed transfer time)
                 h.exchange_end(pending)
+                self._toc(ev_w, which + "_wait")
                 out = self._spmm(a_halo, halo, bias=bias, relu=relu, tag=tag, B2=part, **kw)
                 self.last_recv_bytes[which] = h.last_recv_bytes
                 self._toc(ev, which)

@@ -608,8 +608,10 @@ class DenseMMFunction(torch.autograd.Function):
     products takes 8.7 ms on MI355X (tools/gemm_probe.py) and is at least as accurate (shorter
     fp32 accumulation chains).
 
-    Forward and grad_input use the hand-written MFMA kernel when the layer is 256 -> 256 fp32
-    (gemm_xw256: 8.0 ms vs hipBLASLt 9.95 ms at N = 10⁷), torch.mm otherwise."""
+    Forward and grad_input use the hand-written MFMA kernels when the layer is 256 -> 256 fp32
+    (gemm_xw256: 5.2 ms vs hipBLASLt 9.95 ms at N = 10⁷) or one of the bf16 shapes of gemm_bf16,
+    torch.mm otherwise.  (The one-node training path, pygcn_amd/fused.py, forms the weight
+    gradient with the gather-fused kernel weight_grad_rows instead.)"""
 
     K_SPLIT = K_SPLIT
     MIN_ROWS = MIN_ROWS

@@ -31,6 +31,6 @@ ref = None
 for name, L in libs.items():
     run(L); torch.cuda.synchronize()
     if ref is None: ref = Y[:50000].clone()
-    else: assert torch.equal(Y[:50000], ref), name
+    elif "nostore" not in name: assert torch.equal(Y[:50000], ref), name
 for rnd in range(3):
     print("round %d  " % rnd + "  ".join("%s %.2f" % (n.replace("libgcn_", "").replace(".so", ""), t(lambda: run(L))) for n, L in libs.items()), flush=True)
