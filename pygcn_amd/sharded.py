@@ -15,7 +15,9 @@ same layer (reference pygcn/layers.py:32-38):
     layout, so the gathered buffer is consumed in place: no compaction copy, no all-gather-v.
   * No float atomics, no reduce-scatter of N×F partial sums: each output row is produced by
     exactly one rank.
-  * Exchange modes.  "allgather" moves every row to every rank (P-1)/P·N·F·s bytes in per rank.
+  * Exchange modes.  "allgather" moves every row to every rank ((P-1)/P·N·F·s bytes in per rank),
+    as a direct mesh exchange (one grouped point-to-point round, every block straight to every
+    peer) rather than a ring collective.
     "halo" (default) moves a row only to the ranks whose block references it: at setup every rank
     sends each owner the sorted list of that owner's rows it needs (one grouped P2P round); per
     product the owner packs those rows (index_select) and one grouped isend/irecv round lands them
@@ -401,15 +403,25 @@ class ShardedGraph:
     # ---------------------------------------------------------------- exchange step
     def all_gather_rows(self, local):
         """[n_local, F] on every rank -> padded [P*max_rows, F] (rows past n_local of each slot
-        are never referenced by the remapped column indices)."""
+        are never referenced by the remapped column indices).  A DIRECT (mesh) all-gather: every
+        rank sends its block straight to each of the P-1 peers in one grouped point-to-point
+        round — xGMI is a full mesh of point-to-point links, so all 7 transfers run concurrently
+        at one block-time, where a ring all-gather makes 7 sequential hops over one link
+        (≈ 8.4 ms vs ≈ 58.6 ms for 1.28 GB blocks)."""
         F = local.shape[1]
         out = torch.empty((self.world * self.max_rows, F), dtype=local.dtype, device=local.device)
-        if self.n_local == self.max_rows and local.is_contiguous():
-            slot = local
-        else:
-            slot = torch.zeros((self.max_rows, F), dtype=local.dtype, device=local.device)
-            slot[:self.n_local].copy_(local)
-        dist.all_gather_into_tensor(out, slot, group=self.group)
+        out[self.rank * self.max_rows:self.rank * self.max_rows + self.n_local].copy_(local)
+        if self.world > 1:
+            src = local if local.is_contiguous() else local.contiguous()
+            sends, recvs = [], []
+            for k in range(1, self.world):
+                p = (self.rank + k) % self.world
+                sends.append((src, p))
+            for k in range(1, self.world):
+                q = (self.rank - k) % self.world
+                n_q = self.bounds[q + 1] - self.bounds[q]
+                recvs.append((out[q * self.max_rows:q * self.max_rows + n_q], q))
+            _p2p_round(sends, recvs, self.group)
         return out
 
     def split_block(self, transpose=False):
@@ -512,7 +524,7 @@ class ShardedGraph:
                              tag=tag, B2=halo, **kw)
         else:
             gathered = self.all_gather_rows(local)
-            self.last_recv_bytes[which] = ((self.world - 1) * self.max_rows * local.shape[1]
+            self.last_recv_bytes[which] = ((self.n_global - self.n_local) * local.shape[1]
                                            * local.element_size())
             out = self._spmm(self.At if transpose else self.A, gathered, bias=bias, relu=relu,
                              tag=tag, **kw)
