@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 18
+#define GCN_ABI_VERSION 19
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -326,17 +326,35 @@ int gcn_gemm_xw256_f32(const float *X, int64_t ldx, const float *W, int64_t ldw,
  * x_rows: optional DEVICE int32 list of M row indices — output row r is then the product of input
  * row x_rows[r] (the gradient GEMMs run on the rows that can be non-zero without a compacting
  * copy); NULL = rows 0 .. M-1.
- * mask_src: optional DEVICE fp32 [*, 256] (leading dimension ld_mask): the store becomes
- * y = mask_src[input row, col] > 0 ? y * mask_scale : 0 — the backward of the fused ReLU / dropout
- * epilogue (out > 0 encodes ReLU and keep, scale = 1 / (1 - p)) applied to the grad_input GEMM in
- * its own store; y_absmax then reports the maximum of the masked values.  NULL = plain product.
+ * epilogue: optional store-side options (struct gcn_gemm_epilogue below; NULL = plain product);
+ * y_absmax reports the maximum of the values actually stored.
  * Workspace >= gcn_gemm_xw256_h2_workspace_bytes().  `torch.mm(input, weight)`, pygcn/layers.py:33.
  */
+typedef struct gcn_gemm_epilogue {
+    /* FORWARD epilogue, for a layer evaluated as (Â·X)·W + b — pygcn/layers.py:33-36 reassociated,
+     * the GEMM being the layer's last stage (Fin <= Fout with a constant X: the product Â·X of the
+     * forward pass is then also all the backward pass needs for grad_W, pygcn_amd/fused.py):
+     *   y = acc + bias[col]; y = max(y, 0) if relu; y = keep ? y / (1 - p) : 0 if dropout_p > 0.
+     * The keep bit is the SAME function of (seed, row, col) as in gcn_epilogue (Philox4x32-10), so
+     * a mask does not depend on which kernel stored the element; dropout requires relu. */
+    const float *bias;        /* DEVICE fp32 [256], 16-byte aligned, or NULL */
+    int32_t relu;
+    float dropout_p;          /* in [0, 1); 0 disables dropout */
+    uint64_t seed;
+    const uint64_t *seed_dev; /* optional DEVICE seed read at execution time (hipGraph replays) */
+    /* BACKWARD mask (excludes the forward epilogue): y = mask_src[input row, col] > 0 ? y *
+     * mask_scale : 0 — the backward of a fused ReLU / dropout epilogue (out > 0 encodes ReLU and
+     * keep, scale = 1 / (1 - p)) applied to the grad_input GEMM in its own store. */
+    const float *mask_src;    /* DEVICE fp32 [*, 256] (leading dimension ld_mask) or NULL */
+    int64_t ld_mask;
+    float mask_scale;
+} gcn_gemm_epilogue;
+
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);
 int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
                           int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
-                          float *y_absmax, const float *mask_src, int64_t ld_mask, float mask_scale,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          float *y_absmax, const gcn_gemm_epilogue *epilogue, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /*
  * Y[M, N] = X[M, K] · W[K, N] for bf16 storage (config C5: 128 -> 128): bf16 in / out, fp32

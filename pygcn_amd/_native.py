@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 18
+GCN_ABI_VERSION = 19
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -45,6 +45,14 @@ class GcnEpilogue(ctypes.Structure):
                 ("c_row_nonzero", ctypes.c_void_p), ("log_softmax", ctypes.c_int32),
                 ("seed_dev", ctypes.c_void_p), ("c_row_select", ctypes.c_void_p),
                 ("c_skip_zero_rows", ctypes.c_int32)]
+
+
+class GcnGemmEpilogue(ctypes.Structure):
+    """Mirror of `struct gcn_gemm_epilogue` (include/gcn_spmm.h)."""
+    _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32), ("dropout_p", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p),
+                ("mask_src", ctypes.c_void_p), ("ld_mask", ctypes.c_int64),
+                ("mask_scale", ctypes.c_float)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
@@ -166,8 +174,8 @@ def lib():
     L.gcn_gemm_xw256_f32_h2.restype = ctypes.c_int
     L.gcn_gemm_xw256_f32_h2.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
-                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(GcnGemmEpilogue),
+                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_bf16_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_bf16_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.gcn_gemm_xw_bf16.restype = ctypes.c_int

@@ -361,12 +361,50 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c)
                                                   __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
+// store-side options of gemm_xw256_h2_kernel (host: struct gcn_gemm_epilogue)
+struct H2Epi {
+    const float *bias;          // [256] or NULL
+    int relu;
+    uint32_t drop_thresh;       // keep an element iff its 32 random bits >= drop_thresh (0: none)
+    float drop_scale;           // 1 / (1 - p)
+    uint32_t seed_lo, seed_hi;
+    const uint64_t *seed_dev;   // optional: the seed as of execution time (hipGraph replays)
+    const float *mask_src;      // optional backward mask: y = mask_src > 0 ? y * mask_scale : 0
+    int64_t ld_mask;
+    float mask_scale;
+};
+
+// Philox4x32-10 — the SAME function of (seed, row, f >> 2) as the SpMM epilogue (gcn_spmm.hip):
+// element (row, f) is kept iff word f & 3 >= p * 2^32, whichever kernel stores the element
+__device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                          uint32_t k0, uint32_t k1, uint32_t (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// FWD_EPI = false: plain product / backward mask, persistent with the cross-tile pipeline.
+// FWD_EPI = true: bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
+// the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
+template <bool FWD_EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
     const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
-    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const float *__restrict__ mask_src,
-    int64_t ld_mask, float mask_scale)
+    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
+    const float *__restrict__ mask_src = ep.mask_src;
+    const int64_t ld_mask = ep.ld_mask;
+    const float mask_scale = ep.mask_scale;
     // PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, … and the software
     // pipeline runs ACROSS tile boundaries — the X fragments of the next tile's first steps and
     // its first W stage are already in flight while the current tile's last steps are multiplied
@@ -449,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     float vmax = 0.f;
 
     for (; tile < n_tiles; tile += gridDim.x) {
-        const bool has_next = tile + gridDim.x < n_tiles;      // (uniform over the workgroup)
+        const bool has_next = !FWD_EPI && tile + gridDim.x < n_tiles;      // (uniform over the workgroup)
         // the W image's 32 load addresses are loop-invariant; left visible, hipcc hoists all of
         // them out of the tile loop as 64-bit VGPR pairs and spills 50 registers
         asm volatile("" : "+s"(wl));
@@ -519,12 +557,49 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             float *yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
             const float *mrow = mask_src ? mask_src + src_row * ld_mask + 4 * (lane >> 5) : nullptr;
+            const float *bias_p = ep.bias;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
                                acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
+                    // forward epilogue of the layer when the GEMM is its LAST stage
+                    // ((Â·X)·W + b, pygcn/layers.py:33-36 reassociated): bias, ReLU, inverted dropout
+                    const int f = 32 * nb + 8 * g + 4 * (lane >> 5);          // first of 4 columns
+                    if (FWD_EPI && bias_p != nullptr) {
+                        // the 8 bias values of this column group through the SCALAR cache (uniform
+                        // address), the lane half picks its 4: no per-lane addresses to keep alive
+                        const float *bq = bias_p + 32 * nb + 8 * g;
+                        const bool hi = (lane >> 5) != 0;
+                        v.x += hi ? bq[4] : bq[0];
+                        v.y += hi ? bq[5] : bq[1];
+                        v.z += hi ? bq[6] : bq[2];
+                        v.w += hi ? bq[7] : bq[3];
+                    }
+                    if (FWD_EPI && ep.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (FWD_EPI && ep.drop_thresh != 0u) {                    // (uniform branch)
+                        uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
+                        if (ep.seed_dev != nullptr) {
+                            const uint64_t sd = *ep.seed_dev;
+                            k0 = (uint32_t)sd;
+                            k1 = (uint32_t)(sd >> 32);
+                        }
+                        uint32_t r4[4];
+                        // (opaque: the first Philox round's product of this counter word with its
+                        //  constant does not depend on the tile, and hipcc hoists all 16 of them
+                        //  out of the tile loop — 32 spilled registers)
+                        uint32_t cw = (uint32_t)(f >> 2);
+                        asm volatile("" : "+v"(cw));
+                        h2_philox((uint32_t)row, (uint32_t)(row >> 32), cw, 0u, k0, k1, r4);
+                        v.x = r4[0] >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
+                        v.y = r4[1] >= ep.drop_thresh ? v.y * ep.drop_scale : 0.f;
+                        v.z = r4[2] >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
+                        v.w = r4[3] >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
+                    }
                     if (mrow != nullptr) {
                         const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
                         v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
@@ -537,6 +612,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #endif
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    // (keeps hipcc from running all 32 Philox chains of the tile side by side —
+                    //  128 live registers on top of the accumulators)
+                    if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -848,9 +926,32 @@ size_t gcn_gemm_xw256_h2_workspace_bytes(void)
 
 int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
                           int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
-                          float *y_absmax, const float *mask_src, int64_t ld_mask, float mask_scale,
-                          void *workspace, size_t workspace_bytes, void *stream)
+                          float *y_absmax, const gcn_gemm_epilogue *epi, void *workspace,
+                          size_t workspace_bytes, void *stream)
 {
+    const float *mask_src = epi ? epi->mask_src : nullptr;
+    const int64_t ld_mask = epi ? epi->ld_mask : 0;
+    H2Epi ep = {};
+    if (epi != nullptr) {
+        if (!(epi->dropout_p >= 0.f) || epi->dropout_p >= 1.f)
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: dropout_p must be in [0, 1)");
+        if (epi->dropout_p > 0.f && !epi->relu)
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: dropout needs relu (out > 0 encodes the mask)");
+        if (mask_src != nullptr && (epi->bias != nullptr || epi->relu || epi->dropout_p > 0.f))
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: forward epilogue and backward mask exclude each other");
+        ep.bias = epi->bias;
+        ep.relu = epi->relu ? 1 : 0;
+        ep.drop_thresh = epi->dropout_p > 0.f
+                             ? (uint32_t)std::min(4294967295.0, (double)epi->dropout_p * 4294967296.0) : 0u;
+        if (epi->dropout_p > 0.f && ep.drop_thresh == 0u) ep.drop_thresh = 1u;
+        ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.seed_lo = (uint32_t)epi->seed;
+        ep.seed_hi = (uint32_t)(epi->seed >> 32);
+        ep.seed_dev = epi->seed_dev;
+        ep.mask_src = mask_src;
+        ep.ld_mask = ld_mask;
+        ep.mask_scale = epi->mask_scale;
+    }
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
     if (M == 0) return 0;
@@ -860,15 +961,22 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw256_f32_h2: workspace too small");
     if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 4) != 0 ||
         (ldy % 4) != 0 || (((uintptr_t)x_absmax_bound) | ((uintptr_t)y_absmax)) % 4 != 0 ||
-        ((uintptr_t)mask_src) % 16 != 0 || (mask_src != nullptr && (ld_mask % 4 != 0 || ld_mask < kN)))
+        ((uintptr_t)mask_src) % 16 != 0 || (mask_src != nullptr && (ld_mask % 4 != 0 || ld_mask < kN)) ||
+        ((uintptr_t)ep.bias) % 16 != 0)
         return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32_h2: X / Y rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
-    const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
-    hipLaunchKernelGGL(gemm_xw256_h2_kernel, dim3(grid), dim3(kThreads), 0, s, X, ldx,
-                       x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                       (uint32_t *)y_absmax, mask_src, ld_mask, mask_scale);
+    if (ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u) {
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
+                           x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                           (uint32_t *)y_absmax, ep);
+    } else {
+        const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<false>, dim3(grid), dim3(kThreads), 0, s, X, ldx,
+                           x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                           (uint32_t *)y_absmax, ep);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
     return 0;

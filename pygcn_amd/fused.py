@@ -13,6 +13,8 @@ every later gradient CAN be non-zero follows from the graph alone:
     grad_sup2 = Âᵀ · grad_pre2                 rows  R2 = vertices that have a neighbour in R
     grad_W2   = h1ᵀ · grad_sup2,  grad_h1 = grad_sup2 · W2ᵀ,  grad_pre1 = mask(grad_h1)   rows R2
     grad_W1   = (Â·X)ᵀ · grad_pre1 = (Â·X)[R2]ᵀ · grad_pre1[R2]
+                (Â·X is the first product of the forward pass itself when the layer is evaluated
+                 as (Â·X)·W1 — 256 -> 256 fp32 — so layer 1 needs no sparse product in backward)
 
 `model(features, adj, rows=idx_train)` returns `output[idx_train]` from a node that keeps all of
 this inside: R2 is computed once per (graph, rows) from the CSR structure, every intermediate
@@ -126,23 +128,40 @@ class GCN2RowsFunction(torch.autograd.Function):
         ctx.graph, ctx.rs = graph, rs
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         # bounds of max|operand| for the scaled fp16 GEMM, without a pass over the data:
-        # X is constant (cached), and |relu/dropout(Â·S + b)| <= (‖Â‖∞·max|S| + max|b|) / (1 - p)
+        # X is constant (cached), and |Â·B| <= ‖Â‖∞·max|B|
         bounded = x.dtype == torch.float32
-        s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
         ctx.x_bound = _spmm.absmax_cached(x) if bounded else None
-        sup1 = _dense_forward(x, w1, ctx.x_bound, s_max)
-        h1 = spmm_csr(graph, sup1, bias=b1, relu=True, dropout_p=dropout_p, seed=seed)
-        del sup1
-        h_bound = None
-        if bounded:
-            h_bound = graph.inf_norm() * s_max
-            if b1 is not None:
-                h_bound = h_bound + b1.detach().abs().max().float()
-            h_bound = h_bound * (1.0001 * ctx.scale)
+        # Layer 1 REASSOCIATED when the GEMM kernel can carry the layer's epilogue (256 -> 256 fp32):
+        #     h1 = dropout(relu((Â·X)·W1 + b1))        instead of   dropout(relu(Â·(X·W1) + b1))
+        # — the same two kernels and the same bytes in the forward pass (an SpMM at width 256, a
+        # GEMM), but the product z = Â·X of THIS forward pass is then all the backward pass needs
+        # for grad_W1 = zᵀ·grad_pre1: no second sparse product for layer 1 (12.7 ms at C4).
+        ctx.reassoc = bool(bounded and _spmm._gemm_scheme == "h2" and tuple(w1.shape) == (256, 256)
+                           and x.shape[1] == 256 and x.stride(1) == 1
+                           and (b1 is None or (b1.dtype == torch.float32 and b1.is_contiguous())))
+        h1 = h_bound = z = None
+        if ctx.reassoc:
+            z = spmm_csr(graph, x)
+            ctx.z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
+            h_bound = torch.zeros(1, dtype=torch.float32, device=x.device)   # max|h1|, exact
+            h1 = gemm_xw256(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, dropout_p=dropout_p,
+                            seed=seed)
+            if h1 is None:                     # (alignment the kernel cannot take)
+                ctx.reassoc, z = False, None
+        if h1 is None:
+            s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
+            sup1 = _dense_forward(x, w1, ctx.x_bound, s_max)
+            h1 = spmm_csr(graph, sup1, bias=b1, relu=True, dropout_p=dropout_p, seed=seed)
+            del sup1
+            if bounded:   # |relu/dropout(Â·S + b)| <= (‖Â‖∞·max|S| + max|b|) / (1 - p)
+                h_bound = graph.inf_norm() * s_max
+                if b1 is not None:
+                    h_bound = h_bound + b1.detach().abs().max().float()
+                h_bound = h_bound * (1.0001 * ctx.scale)
         ctx.h_bound = h_bound
         logp = spmm_csr(graph, _dense_forward(h1, w2, h_bound), bias=b2, log_softmax=True)
         out_rows = logp.index_select(0, rows.to(torch.int64))
-        ctx.save_for_backward(x, w1, w2, h1, out_rows)
+        ctx.save_for_backward(z if ctx.reassoc else x, w1, w2, h1, out_rows)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.bias_dtypes = (b1.dtype if b1 is not None else None, b2.dtype if b2 is not None else None)
         if keep_full:
@@ -152,7 +171,7 @@ class GCN2RowsFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_rows, _grad_full):
-        x, w1, w2, h1, out_rows = ctx.saved_tensors
+        x, w1, w2, h1, out_rows = ctx.saved_tensors          # (x is z = Â·X on the reassociated path)
         graph, rs = ctx.graph, ctx.rs
         need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad[:5]
         n, dev, dt = graph.shape[0], x.device, h1.dtype
@@ -213,7 +232,18 @@ class GCN2RowsFunction(torch.autograd.Function):
             grad_b1 = gpre1.float().sum(0).to(ctx.bias_dtypes[0])
         gpre_bound = gh_max if f32 else None
         # ---- layer 1
-        if not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
+        if ctx.reassoc:
+            z = x                                           # this step's Â·X, saved by forward
+            if need_w1:
+                grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, ctx.z_bound,
+                                                 gpre_bound, n_list=rs.n2)
+                if grad_w1 is None:
+                    grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
+            if need_x:                                      # grad_X = Âᵀ·(grad_pre1·W1ᵀ)
+                gz = _dense_forward(gpre1, w1.t().contiguous(), gpre_bound)
+                grad_z = _operand_buffer(n, gz.shape[1], dt, dev, rs.rows2, gz, rs.n2)
+                grad_x = spmm_csr(graph_t, grad_z, tag="bwd", b_hint=rs.hint2)
+        elif not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
             if need_w1:
                 # grad_W1 = (Â·X)[R2]ᵀ · grad_pre1[R2]: a forward product restricted to rows R2
                 z = spmm_csr(graph, x, tag="bwd", c_select=rs.hint2[0],

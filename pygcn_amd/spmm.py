@@ -336,7 +336,8 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
-def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0):
+def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0,
+               bias=None, relu=False, dropout_p=0.0, seed=0):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -349,6 +350,9 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     input row rows[r] — a gather fused into the kernel's loads.  `mask_src` ([*, 256] fp32, read
     at the same input rows): the store becomes mask_src > 0 ? y * mask_scale : 0, the backward of a
     fused ReLU / dropout epilogue, in the GEMM's own store (None if it cannot be fused).
+    `bias` / `relu` / `dropout_p` / `seed`: FORWARD epilogue in the store, y = dropout(relu(acc +
+    bias)) with the same Philox keep function as the SpMM epilogue — for a layer evaluated as
+    (Â·X)·W + b, whose last stage is the GEMM (None if it cannot be fused).
     Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
     product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
     underflow — tests/test_gemm_gpu.py)."""
@@ -357,6 +361,11 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
+    has_fwd_ep = bias is not None or relu or dropout_p > 0.0
+    if has_fwd_ep and (_gemm_scheme != "h2" or mask_src is not None
+                       or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256
+                                                 or not bias.is_contiguous() or bias.data_ptr() % 16))):
+        return None
     if mask_src is not None and (_gemm_scheme != "h2" or mask_src.dtype != torch.float32
                                  or mask_src.dim() != 2 or mask_src.shape[1] != 256
                                  or mask_src.stride(1) != 1 or mask_src.stride(0) % 4
@@ -383,14 +392,22 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                 raise RuntimeError("gemm_xw256: x_bound must be one float32 on the operand's device")
             ws_bytes = L.gcn_gemm_xw256_h2_workspace_bytes()
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+            ep = None
+            if has_fwd_ep or mask_src is not None:
+                seed_dev = None
+                if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
+                    seed_dev, seed = seed.data_ptr(), 0
+                ep = _native.GcnGemmEpilogue(
+                    bias.detach().data_ptr() if bias is not None else None, int(bool(relu)),
+                    float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
+                    mask_src.data_ptr() if mask_src is not None else None,
+                    mask_src.stride(0) if mask_src is not None else 0, float(mask_scale))
             rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0),
                                          rows.data_ptr() if rows is not None else None,
                                          W.data_ptr(), W.stride(0),
                                          Y.data_ptr(), Y.stride(0), m_out, x_bound.data_ptr(),
                                          y_absmax.data_ptr() if y_absmax is not None else None,
-                                         mask_src.data_ptr() if mask_src is not None else None,
-                                         mask_src.stride(0) if mask_src is not None else 0,
-                                         float(mask_scale), ws.data_ptr(), ws_bytes, stream)
+                                         ep, ws.data_ptr(), ws_bytes, stream)
             _native.check(rc, "gcn_gemm_xw256_f32_h2")
             return Y
         ws_bytes = L.gcn_gemm_xw256_workspace_bytes()

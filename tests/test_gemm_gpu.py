@@ -266,3 +266,40 @@ def test_gemm_with_fused_relu_dropout_mask(dev):
     rows = torch.randperm(4000, device=dev)[:999].to(torch.int32)
     got_r = gemm_xw256(X, W, x_bound=b, rows=rows, mask_src=H, mask_scale=2.0)
     assert torch.equal(got_r, want[rows.long()])
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p):
+    """bias + ReLU + inverted dropout in the GEMM's store (a layer evaluated as (Â·X)·W + b): the
+    same values — and the SAME Philox keep bits for a given (seed, row, column) — as the SpMM
+    epilogue applied to the plain product (checked through an identity adjacency)."""
+    from pygcn_amd import CSRGraph, spmm_csr
+    from pygcn_amd.spmm import gemm_xw256
+    gen = torch.Generator(device=dev).manual_seed(12)
+    M = 3001
+    X = torch.randn(M, 256, generator=gen, device=dev)
+    W = torch.randn(256, 256, generator=gen, device=dev) * 0.1
+    bias = torch.randn(256, generator=gen, device=dev)
+    b = X.abs().max().reshape(1)
+    plain = gemm_xw256(X, W, x_bound=b)
+    ident = CSRGraph(torch.arange(M + 1, device=dev, dtype=torch.int32),
+                     torch.arange(M, device=dev, dtype=torch.int32), torch.ones(M, device=dev), (M, M))
+    seed = 0x1234_5678_9ABC_DEF1
+    want = spmm_csr(ident, plain, bias=bias, relu=True, dropout_p=p, seed=seed)
+    ymax = torch.zeros(1, device=dev)
+    got = gemm_xw256(X, W, x_bound=b, y_absmax=ymax, bias=bias, relu=True, dropout_p=p, seed=seed)
+    assert got is not None and torch.equal(got, want)
+    assert float(ymax) == float(want.abs().max())
+    if p > 0:
+        kept = (got != 0).float().mean().item()
+        assert abs(kept - 0.5 * (1 - p)) < 0.02          # ~half survive the ReLU, (1 - p) of those the dropout
+        other = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=p, seed=seed + 1)
+        assert not torch.equal(other, got)
+    # bias only / relu only
+    assert torch.equal(gemm_xw256(X, W, x_bound=b, bias=bias), plain + bias)
+    assert torch.equal(gemm_xw256(X, W, x_bound=b, relu=True), plain.clamp_min(0))
+    # a device-resident seed gives the same mask as the same host seed
+    sd = torch.tensor([seed & (2 ** 63 - 1)], dtype=torch.int64, device=dev)
+    a1 = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.25, seed=sd)
+    a2 = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.25, seed=int(sd.item()))
+    assert torch.equal(a1, a2)
