@@ -198,7 +198,7 @@ class GCN2RowsFunction(torch.autograd.Function):
             return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
         # ---- layer 2: Âᵀ · grad_pre2 restricted to operand rows R and output rows R2
         grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
-        grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd", b_hint=rs.hint, c_select=rs.hint2[0],
+        grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd_l2", b_hint=rs.hint, c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, gp.shape[1]), dt, dev))
         # |Âᵀ·grad_pre2| <= ‖Âᵀ‖∞ · max|grad_pre2|  (max over the small [|R|, C] tensor)
         f32 = dt == torch.float32
@@ -242,11 +242,11 @@ class GCN2RowsFunction(torch.autograd.Function):
             if need_x:                                      # grad_X = Âᵀ·(grad_pre1·W1ᵀ)
                 gz = _dense_forward(gpre1, w1.t().contiguous(), gpre_bound)
                 grad_z = _operand_buffer(n, gz.shape[1], dt, dev, rs.rows2, gz, rs.n2)
-                grad_x = spmm_csr(graph_t, grad_z, tag="bwd", b_hint=rs.hint2)
+                grad_x = spmm_csr(graph_t, grad_z, tag="bwd_l1", b_hint=rs.hint2)
         elif not need_x and x.shape[1] <= 2 * gpre1.shape[1]:
             if need_w1:
                 # grad_W1 = (Â·X)[R2]ᵀ · grad_pre1[R2]: a forward product restricted to rows R2
-                z = spmm_csr(graph, x, tag="bwd", c_select=rs.hint2[0],
+                z = spmm_csr(graph, x, tag="bwd_l1", c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
                 if f32 and _spmm._gemm_scheme == "h2" and x.shape[1] == 256 and gpre1.shape[1] == 256:
                     z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
@@ -256,7 +256,7 @@ class GCN2RowsFunction(torch.autograd.Function):
                     grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
         elif need_x or need_w1:
             grad_pre1 = _operand_buffer(n, gpre1.shape[1], dt, dev, rs.rows2, gpre1, rs.n2)
-            grad_sup1 = spmm_csr(graph_t, grad_pre1, tag="bwd", b_hint=rs.hint2)
+            grad_sup1 = spmm_csr(graph_t, grad_pre1, tag="bwd_l1", b_hint=rs.hint2)
             if need_w1:
                 grad_w1 = _weight_grad(x, grad_sup1)
             if need_x:
