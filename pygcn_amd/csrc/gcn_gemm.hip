@@ -487,7 +487,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     float vmax = 0.f;
 
     for (; tile < n_tiles; tile += gridDim.x) {
-        const bool has_next = !FWD_EPI && tile + gridDim.x < n_tiles;      // (uniform over the workgroup)
+#ifndef GEMM_H2_EPI_PERSIST
+#define GEMM_H2_EPI_PERSIST 1
+#endif
+        const bool has_next = (!FWD_EPI || GEMM_H2_EPI_PERSIST) && tile + gridDim.x < n_tiles;   // (uniform)
         // the W image's 32 load addresses are loop-invariant; left visible, hipcc hoists all of
         // them out of the tile loop as 64-bit VGPR pairs and spills 50 registers
         asm volatile("" : "+s"(wl));
@@ -968,7 +971,9 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
     if (ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u) {
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3((unsigned)tiles), dim3(kThreads), 0, s, X, ldx,
+        const unsigned egrid = GEMM_H2_EPI_PERSIST ? (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID)
+                                                   : (unsigned)tiles;
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3(egrid), dim3(kThreads), 0, s, X, ldx,
                            x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                            (uint32_t *)y_absmax, ep);
     } else {
