@@ -335,7 +335,7 @@ typedef struct gcn_gemm_epilogue {
      * the GEMM being the layer's last stage (Fin <= Fout with a constant X: the product Â·X of the
      * forward pass is then also all the backward pass needs for grad_W, pygcn_amd/fused.py):
      *   y = acc + bias[col]; y = max(y, 0) if relu; y = keep ? y / (1 - p) : 0 if dropout_p > 0.
-     * The keep bit is the SAME function of (seed, row, col) as in gcn_epilogue (Philox4x32-10), so
+     * The keep bit is the SAME function of (seed, row, col) as in struct gcn_epilogue — Philox4x32-10 — so
      * a mask does not depend on which kernel stored the element; dropout requires relu. */
     const float *bias;        /* DEVICE fp32 [256], 16-byte aligned, or NULL */
     int32_t relu;

@@ -206,7 +206,8 @@ def test_ctypes_structs_follow_the_header_field_by_field():
     hdr = open(os.path.join(ROOT, "include", "gcn_spmm.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     width = {"int32_t": 4, "int64_t": 8, "uint64_t": 8, "float": 4}
-    for cname, mirror in (("gcn_csr_plan", _native.GcnCsrPlan), ("gcn_epilogue", _native.GcnEpilogue)):
+    for cname, mirror in (("gcn_csr_plan", _native.GcnCsrPlan), ("gcn_epilogue", _native.GcnEpilogue),
+                          ("gcn_gemm_epilogue", _native.GcnGemmEpilogue)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
         fields = []
         for decl in body.split(";"):
