@@ -601,13 +601,31 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         ctx.relu = bool(relu)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         ev = sg._tic(x_local)
-        sup_own = _dense_forward(x_local, weight)
-        sup_halo = _dense_forward(x_halo, weight) if x_halo.shape[0] else \
-            x_halo.new_empty((0, weight.shape[1]))
         kw = {"dropout_p": dropout_p, "seed": seed + sg.rank} if dropout_p > 0.0 else {}
-        out = sg._spmm(sg.A, sup_own, bias=bias, relu=relu, tag="fwd_local", B2=sup_halo, **kw)
+        # REASSOCIATED where the GEMM kernel can carry the epilogue (256 -> 256 fp32, HIP):
+        #     out_r = epilogue((Â_r · [X_r ; X_halo]) · W + b)
+        # — the same local product at the same width, then ONE GEMM over the rank's own rows (the
+        # GEMM of the halo rows disappears), and z_r = Â_r·[X_r ; X_halo] of this forward pass is all
+        # the backward pass needs for grad_W (no local product in backward either).
+        out = z = None
+        if (sg._hinted_product and x_local.is_cuda and x_local.dtype == torch.float32
+                and tuple(weight.shape) == (256, 256) and x_local.shape[1] == 256
+                and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+            from .spmm import absmax_cached, gemm_xw256
+            z = sg._spmm(sg.A, x_local, tag="fwd_local", B2=x_halo)
+            xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
+                x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
+            out = gemm_xw256(z, weight, sg.A.inf_norm() * xb * 1.0001, bias=bias, relu=relu, **kw)
+            if out is None:
+                z = None
+        ctx.reassoc = out is not None
+        if out is None:
+            sup_own = _dense_forward(x_local, weight)
+            sup_halo = _dense_forward(x_halo, weight) if x_halo.shape[0] else \
+                x_halo.new_empty((0, weight.shape[1]))
+            out = sg._spmm(sg.A, sup_own, bias=bias, relu=relu, tag="fwd_local", B2=sup_halo, **kw)
         sg._toc(ev, "fwd")
-        ctx.save_for_backward(x_local, x_halo, weight, *([out] if relu else []))
+        ctx.save_for_backward(z if ctx.reassoc else x_local, x_halo, weight, *([out] if relu else []))
         return out
 
     @staticmethod
@@ -618,7 +636,9 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         grad_pre, grad_bias, hint = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
                                             ctx.has_bias and ctx.needs_input_grad[4])
         grad_w = None
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and ctx.reassoc:
+            grad_w = _weight_grad(x_local, grad_pre.contiguous())     # (x_local is z_r = Â_r·X here)
+        elif ctx.needs_input_grad[3]:
             grad_pre = grad_pre.contiguous()
             # rows of Â_r · X that meet an all-zero row of grad_pre add nothing: with the bitmap
             # of the fused backward pass the product computes only the others (c_select) and the
