@@ -71,8 +71,11 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
             assert err <= rel * b.double().abs().max().item(), f"rank {rank}: {what} {err:.3e}"
         close(logp, rl[sg.r0:sg.r1], "logp block")
         assert abs(gl - rloss.item()) <= 1e-5 * abs(rloss.item())
+        # parameter gradients are fp32 sums over 60 000 rows formed in two different association
+        # orders here — sharded: (Â_r·X)ᵀ·grad per rank, then summed over ranks; single GPU, loss
+        # over all rows: Xᵀ·(Âᵀ·grad) — each within 2e-5 of the exact value, so 5e-5 apart
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-            close(p.grad, q.grad, k + ".grad", rel=2e-5)
+            close(p.grad, q.grad, k + ".grad", rel=5e-5)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
