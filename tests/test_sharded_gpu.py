@@ -51,7 +51,10 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
         model = GCN(F, F, F, dropout=0.0).to(dev)
         smodel = ShardedGCN(model, sg)
         model.train()
+        h1 = {}
+        hook = model.gc1.register_forward_hook(lambda m, i, o: h1.__setitem__("sharded", o.detach()))
         logp = smodel(x[sg.r0:sg.r1].to(dev), sg)
+        hook.remove()
         loss = smodel.nll_loss(logp, labels[sg.r0:sg.r1].to(dev))
         loss.backward()
         smodel.allreduce_grads()
@@ -62,20 +65,42 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
         ref = GCN(F, F, F, dropout=0.0).to(dev)
         ref.train()
         g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+
+        def keep(m, i, o):
+            h1["ref"] = o.detach()
+            o.register_hook(lambda gr: h1.__setitem__("ref_grad", gr.detach()))
+        hook = ref.gc1.register_forward_hook(keep)
         rl = ref(x.to(dev), g)
+        hook.remove()
         rloss = torch.nn.functional.nll_loss(rl, labels.to(dev))
         rloss.backward()
 
-        def close(a, b, what, rel=1e-5):
+        def close(a, b, what, rel=1e-5, extra=0.0):
             err = (a.double() - b.double()).abs().max().item()
-            assert err <= rel * b.double().abs().max().item(), f"rank {rank}: {what} {err:.3e}"
+            scale = b.double().abs().max().item()
+            assert err <= rel * scale + extra, \
+                f"rank {rank}: {what} {err:.3e} vs scale {scale:.3e} (+{extra:.3e})"
         close(logp, rl[sg.r0:sg.r1], "logp block")
+        close(h1["sharded"], h1["ref"][sg.r0:sg.r1], "hidden block")
         assert abs(gl - rloss.item()) <= 1e-5 * abs(rloss.item())
-        # parameter gradients are fp32 sums over 60 000 rows formed in two different association
-        # orders here — sharded: (Â_r·X)ᵀ·grad per rank, then summed over ranks; single GPU, loss
-        # over all rows: Xᵀ·(Âᵀ·grad) — each within 2e-5 of the exact value, so 5e-5 apart
+        # The two paths associate layer 1 differently (sharded: (Â_r·X)·W, single GPU with the loss
+        # on all rows: Â·(X·W)), so pre-activations within rounding of zero land on different sides
+        # of the ReLU.  The loss is not differentiable there: each such element (r, j) moves
+        # gc1.weight.grad[:, j] by grad_h1[r, j] · (Â·X)[r, :] and gc1.bias.grad[j] by grad_h1[r, j].
+        # Those elements are identified and priced exactly; everything else must agree to 5e-5
+        # (fp32 sums over 60 000 rows in two association orders, each within 2e-5 of exact).
+        from pygcn_amd.spmm import spmm_csr
+        hs, hr = h1["sharded"], h1["ref"][sg.r0:sg.r1]
+        flips = (hs > 0) != (hr > 0)
+        assert int(flips.sum()) <= 1e-4 * flips.numel()
+        assert (torch.maximum(hs, hr) * flips).max().item() <= 1e-5 * hr.max().item()
+        gh = h1["ref_grad"][sg.r0:sg.r1].abs() * flips
+        zmax = spmm_csr(g, x.to(dev))[sg.r0:sg.r1].abs().amax(1, keepdim=True)
+        budget = torch.stack([(gh * zmax).sum(0), gh.sum(0)]).cpu()
+        dist.all_reduce(budget)
+        extra = {"gc1.weight": budget[0].max().item(), "gc1.bias": budget[1].max().item()}
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-            close(p.grad, q.grad, k + ".grad", rel=5e-5)
+            close(p.grad, q.grad, k + ".grad", rel=5e-5, extra=extra.get(k, 0.0))
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
