@@ -405,6 +405,8 @@ def main():
     if l2 or l1:      # one-node path: launches are tagged by layer (layer 1 may need none at all)
         bwd_l2 = float(np.mean(l2)) if l2 else 0.0
         bwd_l1 = float(np.sum(l1)) / max(1, len(l2)) if l1 else 0.0
+    elif plain and len(plain) == args.steps:   # sharded, layer 1 reassociated: layer 2 only
+        bwd_l2, bwd_l1 = float(np.mean(plain)), 0.0
     else:             # layer-by-layer / sharded path: layer 2 first, then layer 1, every epoch
         bwd_l2 = float(np.mean(plain[0::2])) if len(plain) >= 2 else float("nan")
         bwd_l1 = float(np.mean(plain[1::2])) if len(plain) >= 2 else float("nan")
@@ -498,8 +500,9 @@ def main():
                                        f"{adj.exchange_rows()[1]} remote rows per dense exchange"
                                        + ("; the halo rows of the constant feature matrix are "
                                           "exchanged once before the timed region and held (like "
-                                          "the adjacency block), so layer 1 recomputes their GEMM "
-                                          "locally instead of exchanging: 2 exchanges per epoch "
+                                          "the adjacency block), so layer 1 is the local product "
+                                          "A_r x [X_r ; X_halo] followed by one GEMM over the "
+                                          "rank's own rows, without an exchange: 2 exchanges per epoch "
                                           "(layer 2 forward dense, layer 2 backward non-zero rows only), not 4"
                                           if args.exchange == "halo" else ""))
                        if world > 1 else "single GPU",
@@ -525,7 +528,7 @@ def main():
                               "forward pass and needs no sparse product in backward (0 ms); `value` "
                               "and `roofline` are the unrestricted forward products; the "
                               "dense-gradient epoch is reported beside it") if world == 1 else
-                             "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: local A_r x X product, no exchange (pygcn_amd/sharded.py)",
+                             "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: none (grad_W1 = (A_r x X)^T x grad_pre reuses the forward pass's A_r x X) (pygcn_amd/sharded.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),

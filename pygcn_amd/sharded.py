@@ -613,6 +613,8 @@ class ShardedInputLayerFunction(torch.autograd.Function):
                 and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
             from .spmm import absmax_cached, gemm_xw256
             z = sg._spmm(sg.A, x_local, tag="fwd_local", B2=x_halo)
+            sg._toc(ev, "fwd")       # (the window of the product, as in the other branch)
+            ev = None
             xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
                 x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
             out = gemm_xw256(z, weight, sg.A.inf_norm() * xb * 1.0001, bias=bias, relu=relu, **kw)
@@ -623,8 +625,9 @@ class ShardedInputLayerFunction(torch.autograd.Function):
             sup_own = _dense_forward(x_local, weight)
             sup_halo = _dense_forward(x_halo, weight) if x_halo.shape[0] else \
                 x_halo.new_empty((0, weight.shape[1]))
+            ev = sg._tic(sup_own)
             out = sg._spmm(sg.A, sup_own, bias=bias, relu=relu, tag="fwd_local", B2=sup_halo, **kw)
-        sg._toc(ev, "fwd")
+            sg._toc(ev, "fwd")
         ctx.save_for_backward(z if ctx.reassoc else x_local, x_halo, weight, *([out] if relu else []))
         return out
 
