@@ -681,8 +681,11 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
         // (opaque per tile: otherwise hipcc hoists every W fragment out of the tile loop into
         //  registers — 128..512 VGPRs — and the kernel runs at one wave per SIMD)
-        const unsigned char *wl = wlds;
-        asm volatile("" : "+v"(wl));
+        //  (an opaque OFFSET: an opaque pointer would leave the LDS address space and turn the
+        //  reads into flat loads)
+        uint32_t wofs = 0;
+        asm volatile("" : "+v"(wofs));
+        const unsigned char *wl = wlds + wofs;
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
 #pragma unroll

@@ -13,12 +13,12 @@ for path in sys.argv[1:]:
     L.gcn_gemm_xw256_f32_h2.restype = ctypes.c_int
     L.gcn_gemm_xw256_f32_h2.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     libs[os.path.basename(path)] = L
 ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
 def run(L):
     rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), 256, None, W.data_ptr(), 256, Y.data_ptr(), 256, M, b.data_ptr(), None,
-                                 None, 0, 1.0, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                                 None, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
 def t(fn, reps=5):
     fn(); torch.cuda.synchronize()
@@ -31,6 +31,6 @@ ref = None
 for name, L in libs.items():
     run(L); torch.cuda.synchronize()
     if ref is None: ref = Y[:50000].clone()
-    elif "nostore" not in name: assert torch.equal(Y[:50000], ref), name
+    elif "nostore" not in name and "diag1" not in name: assert torch.equal(Y[:50000], ref), name
 for rnd in range(3):
     print("round %d  " % rnd + "  ".join("%s %.2f" % (n.replace("libgcn_", "").replace(".so", ""), t(lambda: run(L))) for n, L in libs.items()), flush=True)
