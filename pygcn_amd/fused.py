@@ -61,6 +61,13 @@ class RowSets:
         self.rows_u, self.inverse = torch.unique(rows, return_inverse=True)      # sorted
         self.has_duplicates = self.rows_u.numel() != rows.numel()
         self.n_u = int(self.rows_u.numel())
+        # upstream's idx_train is a range (utils.py:370 `range(140)`): rows r0, r0+1, … in order.
+        # The loss gradient is then written straight into its rows of the [N, C] operand buffer.
+        self.range_start = None
+        if self.n_u and not self.has_duplicates:
+            r0 = int(rows[0])
+            if bool((rows == torch.arange(r0, r0 + self.n_u, device=dev)).all()):
+                self.range_start = r0
         mask = torch.zeros(n, dtype=torch.bool, device=dev)
         mask[self.rows_u] = True
         self.hint = pack_row_flags(mask)                                         # (bitmap, count)
@@ -113,7 +120,8 @@ def _operand_buffer(n, width, dtype, device, rows, values, count):
     zero otherwise."""
     buf = _maybe_poisoned((n, width), dtype, device) if _rows_honoured(n, width, dtype, count) \
         else torch.zeros((n, width), dtype=dtype, device=device)
-    buf.index_copy_(0, rows, values)
+    if rows is not None:           # (None: the caller writes the rows itself)
+        buf.index_copy_(0, rows, values)
     return buf
 
 
@@ -178,7 +186,13 @@ class GCN2RowsFunction(torch.autograd.Function):
         graph_t = graph.t()
         # ---- loss rows: log_softmax backward on the compact [|R|, C] tensors — one HIP pass
         # (gcn_log_softmax_backward_colsum: grad_pre and the bias gradient's column sums together)
-        one_pass = _spmm.backward_with_colsum(grad_rows.contiguous(), out_rows, log_softmax=True) \
+        grad_pre2 = None
+        if rs.range_start is not None and grad_rows.dtype == dt:
+            # rows R are a range: the kernel writes grad_pre2's rows where the product reads them
+            grad_pre2 = _operand_buffer(n, grad_rows.shape[1], dt, dev, None, None, rs.n_u)
+        one_pass = _spmm.backward_with_colsum(
+            grad_rows.contiguous(), out_rows, log_softmax=True,
+            dest=None if grad_pre2 is None else grad_pre2[rs.range_start:rs.range_start + rs.n_u]) \
             if (grad_rows.dtype == out_rows.dtype and not rs.has_duplicates) else None
         if one_pass is not None:
             gp, colsum, _ = one_pass
@@ -197,7 +211,8 @@ class GCN2RowsFunction(torch.autograd.Function):
         if not (need_x or need_w1 or need_b1 or need_w2):
             return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
         # ---- layer 2: Âᵀ · grad_pre2 restricted to operand rows R and output rows R2
-        grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
+        if grad_pre2 is None or one_pass is None:
+            grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
         grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd_l2", b_hint=rs.hint, c_select=rs.hint2[0],
                              out=_maybe_poisoned((n, gp.shape[1]), dt, dev))
         # |Âᵀ·grad_pre2| <= ‖Âᵀ‖∞ · max|grad_pre2|  (max over the small [|R|, C] tensor)
@@ -229,7 +244,8 @@ class GCN2RowsFunction(torch.autograd.Function):
             del gh1
         del gs2, h1c, grad_pre2, grad_sup2
         if ctx.has_bias[0] and need_b1:
-            grad_b1 = gpre1.float().sum(0).to(ctx.bias_dtypes[0])
+            sums = _spmm.backward_with_colsum(gpre1) if gpre1.is_contiguous() else None   # (one HIP pass)
+            grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])
         gpre_bound = gh_max if f32 else None
         # ---- layer 1
         if ctx.reassoc:

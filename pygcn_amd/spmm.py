@@ -155,7 +155,8 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
     return res
 
 
-def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_zero_rows=False):
+def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_zero_rows=False,
+                         dest=None):
     """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 / bf16 [N, F]
     tensors (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
     `log_softmax=True`: `out` holds log-probabilities and grad_pre = grad_out - exp(out) *
@@ -165,6 +166,8 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_
     `skip_zero_rows=True` (needs `out` and a hint): rows of grad_pre that are entirely zero are
     NOT written — only the rows whose hint bit is set are defined; for consumers that read those
     rows only.
+    `dest` (needs `out`): a contiguous tensor of grad_out's shape and dtype that receives grad_pre
+    (e.g. a row range of a larger operand buffer) instead of a fresh one.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
     _require_cuda(grad_out, "grad_out")
@@ -179,8 +182,11 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_
                                  or grad_out.shape[1] // (16 // grad_out.element_size()) > 64))):
         return None
     n, F = grad_out.shape
-    grad_pre = _maybe_poisoned(grad_out.shape, grad_out.dtype, grad_out.device) if out is not None \
-        else grad_out
+    if dest is not None and (out is None or dest.shape != grad_out.shape or dest.dtype != grad_out.dtype
+                             or dest.device != grad_out.device or not dest.is_contiguous()):
+        raise RuntimeError("backward_with_colsum: dest must be a contiguous tensor like grad_out (and needs out)")
+    grad_pre = dest if dest is not None else (
+        _maybe_poisoned(grad_out.shape, grad_out.dtype, grad_out.device) if out is not None else grad_out)
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
     hint = None
     if F <= (256 if grad_out.dtype == torch.float32 else 512):   # a row lives inside one wavefront

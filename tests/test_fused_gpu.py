@@ -91,6 +91,25 @@ def test_rmat_step_matches_oracle(oracle, dev, poison, fin, hid, ncls, share):
     _check(model, x, g, a, labels, idx, oracle)
 
 
+@pytest.mark.parametrize("start,count", [(0, 1500), (1234, 4000), (29000, 1000)])
+def test_loss_rows_that_are_a_range(oracle, dev, poison, start, count):
+    """upstream's idx_train is `range(140)` (utils.py:370): for a range the log_softmax backward
+    writes the loss gradient straight into its rows of the [N, C] operand (no compact copy)."""
+    from pygcn_amd import GCN, CSRGraph, fused
+    from pygcn_amd.utils import rmat_graph
+    n = 30000
+    rowptr, col, val = rmat_graph(n, 300000, seed=22, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, 256), 6)).to(dev)
+    labels = np.random.default_rng(start).integers(0, 256, n)
+    idx = np.arange(start, start + count)
+    assert fused.row_sets(g, torch.from_numpy(idx).to(dev)).range_start == start
+    torch.manual_seed(2)
+    model = GCN(256, 256, 256, dropout=0.0).to(dev)
+    _check(model, x, g, a, labels, idx, oracle)
+
+
 def test_duplicate_rows_input_gradient_and_dropout(oracle, dev, poison):
     from pygcn_amd import GCN, CSRGraph
     from pygcn_amd import spmm as S
