@@ -702,6 +702,24 @@ class GraphConvFunction(torch.autograd.Function):
         #  computed once and reused as the scaled GEMM's bound)
         x_bound = absmax_cached(input) if (input.dtype == torch.float32 and not input.requires_grad
                                            and input.is_cuda) else None
+        # REASSOCIATED for a constant input on the shape the GEMM kernel carries the epilogue for
+        # (256 -> 256 fp32): out = epilogue((A·input)·W + b).  Same two kernels and bytes in
+        # forward; z = A·input of this forward pass is then all the backward pass needs for
+        # grad_W = zᵀ·grad_pre — no sparse product in backward (pygcn_amd/fused.py does the same
+        # inside the one-node path).
+        ctx.reassoc = False
+        if (x_bound is not None and _gemm_scheme == "h2" and not log_softmax and input.dim() == 2
+                and tuple(weight.shape) == (256, 256) and weight.dtype == torch.float32
+                and input.shape[1] == 256 and input.stride(1) == 1 and isinstance(graph, CSRGraph)
+                and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+            z = spmm_csr(graph, input)
+            ctx.z_bound = graph.inf_norm() * x_bound * 1.0001
+            out = gemm_xw256(z, weight, ctx.z_bound, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
+            if out is not None:
+                ctx.reassoc = True
+                ctx.save_for_backward(z, weight, *([out] if relu else []))
+                return out
+            del z
         support = _dense_forward(input, weight, x_bound)
         out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
                        log_softmax=log_softmax)
@@ -728,6 +746,24 @@ class GraphConvFunction(torch.autograd.Function):
                                                        ctx.log_softmax, skip_zero_rows=sync_ok)
         if not (need_in or need_w):
             return None, None, grad_bias, None, None, None, None, None
+        if ctx.reassoc:          # (input is z = A·x here; x itself needs no gradient)
+            z, grad_w = input, None
+            if sync_ok and hint is not None:
+                nz_rows = int(hint[1].item())
+                if nz_rows * 3 < grad_pre.shape[0]:      # row-sparse gradient: the listed rows only
+                    rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
+                    lst = padded_row_list(rows)
+                    grad_w = weight_grad_rows(z, grad_pre, lst, lst, ctx.z_bound, None, n_list=nz_rows)
+                    if grad_w is None:
+                        grad_w = _weight_grad(z.index_select(0, rows), grad_pre.index_select(0, rows))
+                elif ctx.relu:       # rows of grad_pre whose bit is clear were not written
+                    keep = unpack_row_flags(hint[0], grad_pre.shape[0])[:, None]
+                    grad_pre = torch.where(keep, grad_pre, torch.zeros_like(grad_pre[:1]))
+            if grad_w is None:
+                grad_pre = grad_pre.contiguous()
+                grad_w = _weight_grad(z, grad_pre, ctx.z_bound,
+                                      torch.linalg.vector_norm(grad_pre, ord=float("inf")).reshape(1))
+            return None, grad_w, grad_bias, None, None, None, None, None
         c_flags = rows = None
         compact = sync_ok and hint is not None
         unwritten = compact and (ctx.relu or ctx.log_softmax)   # grad_pre: flagged rows only

@@ -1000,9 +1000,14 @@ def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
         spmm_csr(g, B, c_select=bits[:-1])
 
 
-def test_first_layer_weight_gradient_through_row_selected_product(oracle, dev):
-    """With a row-sparse grad_pre the first layer forms grad_W = (A·X)ᵀ·grad_pre from a
-    row-selected forward product; same gradients as the transpose-product path."""
+@pytest.mark.parametrize("width,how", [(256, "reassociated"), (128, "row-selected")])
+def test_first_layer_weight_gradient_without_a_transpose_product(oracle, dev, width, how):
+    """A first layer (its input needs no gradient) under a row-sparse grad_pre forms
+    grad_W = (A·X)ᵀ·grad_pre: at 256 -> 256 fp32 the layer is evaluated as (A·X)·W and keeps A·X
+    from its forward pass (no sparse product in backward at all); other widths run a forward
+    product restricted to the rows grad_pre is non-zero on.  Same gradients as the
+    transpose-product path (taken with row compaction off and the three-part GEMM scheme, which
+    switches the reassociation off)."""
     import importlib
     from pygcn_amd import CSRGraph, GraphConvolution
     from pygcn_amd.utils import rmat_graph
@@ -1011,34 +1016,39 @@ def test_first_layer_weight_gradient_through_row_selected_product(oracle, dev):
     rowptr, col, val = rmat_graph(n, 4 * n, seed=6, device=dev)
     g = CSRGraph(rowptr, col, val, (n, n))
     torch.manual_seed(0)
-    layer = GraphConvolution(256, 256).to(dev)
-    x = torch.randn(n, 256, device=dev)
+    layer = GraphConvolution(width, width).to(dev)
+    x = torch.randn(n, width, device=dev)
     idx = torch.randperm(n, device=dev)[: n // 20]
-    tgt = torch.randn(idx.numel(), 256, device=dev)
+    tgt = torch.randn(idx.numel(), width, device=dev)
 
-    def grads(compaction):
+    def grads(compaction, scheme):
         S.set_row_compaction(compaction)
+        S.set_gemm_scheme(scheme)
         S._poison_unwritten = True
         try:
             layer.zero_grad()
             seen = []
             orig = S.spmm_csr
-            S.spmm_csr = lambda *a_, **k: (seen.append(k.get("c_select") is not None), orig(*a_, **k))[1]
+            S.spmm_csr = lambda *a_, **k: (seen.append((k.get("tag", "fwd"), k.get("c_select") is not None)),
+                                           orig(*a_, **k))[1]
             try:
                 torch.manual_seed(1)
                 ((layer(x, g, relu=True)[idx] - tgt) ** 2).sum().backward()
             finally:
                 S.spmm_csr = orig
-            return [p.grad.clone() for p in layer.parameters()], any(seen)
+            return [p.grad.clone() for p in layer.parameters()], seen
         finally:
             S.set_row_compaction(True)
+            S.set_gemm_scheme("h2")
             S._poison_unwritten = False
 
-    sel, used = grads(True)
-    ref, used_ref = grads(False)
-    assert used and not used_ref
-    for a_, b_ in zip(sel, ref):
-        assert_normwise(a_.cpu(), b_.cpu().numpy(), TOL, "row-selected grad_W")
+    new, seen = grads(True, "h2")
+    ref, seen_ref = grads(False, "bf16x3")
+    backward = [sel for tag, sel in seen if tag == "bwd"]
+    assert backward == ([] if how == "reassociated" else [True]), seen
+    assert [sel for tag, sel in seen_ref if tag == "bwd"] == [False], seen_ref
+    for a_, b_ in zip(new, ref):
+        assert_normwise(a_.cpu(), b_.cpu().numpy(), 2e-5, how + " grad")
 
 
 @pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (128, torch.bfloat16)])
