@@ -70,6 +70,9 @@ def parse():
                     help="storage type of features / activations / parameters (values and "
                          "accumulation stay fp32); default: the config's")
     ap.add_argument("--dropout", type=float, default=0.5)
+    ap.add_argument("--reference-call", action="store_true",
+                    help="profiling aid: the timed epoch uses upstream's unchanged lines "
+                         "(model(features, adj); nll_loss(output[idx_train], ...)) instead of rows=")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed side measurements (free-running and dense-loss epochs)")
@@ -359,7 +362,7 @@ def main():
             return
         if snapshot is not None:
             restore_snapshot()
-        epoch()
+        epoch(reference_call=args.reference_call)
 
     def timed(k, fn):
         """K calls of fn bracketed by barrier + synchronize; returns (wall seconds, per-call ms from
@@ -528,7 +531,8 @@ def main():
                                           "(layer 2 forward dense, layer 2 backward non-zero rows only), not 4"
                                           if args.exchange == "halo" else ""))
                        if world > 1 else "single GPU",
-                       "mode": "spmm-only" if args.spmm_only else "train-epoch"},
+                       "mode": "spmm-only" if args.spmm_only else
+                               ("train-epoch (upstream's unchanged lines)" if args.reference_call else "train-epoch")},
             "stationary": ("parameters + Adam state restored from the post-warm-up snapshot at the "
                            "start of every timed epoch (inside the timed region): every timed "
                            "epoch is epoch warmup+1") if snapshot is not None else None,

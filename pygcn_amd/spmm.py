@@ -557,6 +557,29 @@ def absmax_cached(t):
     return hit[2]
 
 
+_absmax_known = {}
+
+
+def remember_absmax(t, value):
+    """Record max|t| (a DEVICE float [1] a kernel produced as a side result, e.g. the GEMM's
+    y_absmax) for the tensor OBJECT t at its current version, so that the next layer's GEMM needs
+    no reduction pass over t.  A few entries per device; weak references, like absmax_cached."""
+    import weakref
+    key = t.device.index if t.device.index is not None else -1
+    known = [e for e in _absmax_known.get(key, []) if e[0]() is not None][-3:]
+    known.append((weakref.ref(t), t._version, value))
+    _absmax_known[key] = known
+
+
+def known_absmax(t):
+    """The bound remember_absmax() recorded for this tensor object and version, or None."""
+    key = t.device.index if t.device.index is not None else -1
+    for ref, version, value in _absmax_known.get(key, ()):
+        if ref() is t and version == t._version:
+            return value
+    return None
+
+
 def _dense_forward(input, weight, x_bound=None, y_absmax=None):
     out = gemm_xw256(input, weight, x_bound, y_absmax)
     if out is None and y_absmax is None:
@@ -702,20 +725,26 @@ class GraphConvFunction(torch.autograd.Function):
         #  computed once and reused as the scaled GEMM's bound)
         x_bound = absmax_cached(input) if (input.dtype == torch.float32 and not input.requires_grad
                                            and input.is_cuda) else None
+        const_input = x_bound is not None
+        if x_bound is None and input.dtype == torch.float32 and input.is_cuda:
+            x_bound = known_absmax(input)       # (left by the layer that produced this tensor)
         # REASSOCIATED for a constant input on the shape the GEMM kernel carries the epilogue for
         # (256 -> 256 fp32): out = epilogue((A·input)·W + b).  Same two kernels and bytes in
         # forward; z = A·input of this forward pass is then all the backward pass needs for
         # grad_W = zᵀ·grad_pre — no sparse product in backward (pygcn_amd/fused.py does the same
         # inside the one-node path).
         ctx.reassoc = False
-        if (x_bound is not None and _gemm_scheme == "h2" and not log_softmax and input.dim() == 2
+        if (const_input and _gemm_scheme == "h2" and not log_softmax and input.dim() == 2
                 and tuple(weight.shape) == (256, 256) and weight.dtype == torch.float32
                 and input.shape[1] == 256 and input.stride(1) == 1 and isinstance(graph, CSRGraph)
                 and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
             z = spmm_csr(graph, input)
             ctx.z_bound = graph.inf_norm() * x_bound * 1.0001
-            out = gemm_xw256(z, weight, ctx.z_bound, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
+            y_max = torch.zeros(1, dtype=torch.float32, device=input.device)
+            out = gemm_xw256(z, weight, ctx.z_bound, y_max, bias=bias, relu=relu, dropout_p=dropout_p,
+                             seed=seed)
             if out is not None:
+                remember_absmax(out, y_max)      # the next layer's GEMM scales by it
                 ctx.reassoc = True
                 ctx.save_for_backward(z, weight, *([out] if relu else []))
                 return out

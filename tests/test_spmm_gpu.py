@@ -1000,6 +1000,29 @@ def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
         spmm_csr(g, B, c_select=bits[:-1])
 
 
+def test_layer_output_carries_its_maximum_to_the_next_layer(dev):
+    """The GEMM that ends a reassociated layer leaves max|out| for the tensor object it returns;
+    the next layer's scaled GEMM picks it up instead of reducing over [N, 256] again.  The record is
+    bound to the object AND its version."""
+    import importlib
+    from pygcn_amd import CSRGraph, GraphConvolution
+    from pygcn_amd.utils import rmat_graph
+    S = importlib.import_module("pygcn_amd.spmm")
+    n = 20000
+    rowptr, col, val = rmat_graph(n, 8 * n, seed=3, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    torch.manual_seed(0)
+    layer = GraphConvolution(256, 256).to(dev)
+    x = torch.randn(n, 256, device=dev)
+    h = layer(x, g, relu=True)
+    known = S.known_absmax(h)
+    assert known is not None and known.item() == h.detach().abs().max().item()
+    assert S.known_absmax(h.detach().clone()) is None
+    with torch.no_grad():
+        h.add_(1.0)
+    assert S.known_absmax(h) is None
+
+
 @pytest.mark.parametrize("width,how", [(256, "reassociated"), (128, "row-selected")])
 def test_first_layer_weight_gradient_without_a_transpose_product(oracle, dev, width, how):
     """A first layer (its input needs no gradient) under a row-sparse grad_pre forms
