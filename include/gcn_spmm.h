@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 19
+#define GCN_ABI_VERSION 20
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -337,7 +337,7 @@ typedef struct gcn_gemm_epilogue {
      *   y = acc + bias[col]; y = max(y, 0) if relu; y = keep ? y / (1 - p) : 0 if dropout_p > 0.
      * The keep bit is the SAME function of (seed, row, col) as in struct gcn_epilogue — Philox4x32-10 — so
      * a mask does not depend on which kernel stored the element; dropout requires relu. */
-    const float *bias;        /* DEVICE fp32 [256], 16-byte aligned, or NULL */
+    const float *bias;        /* DEVICE fp32 [N] (N = 256 for the fp32 kernel), 16-byte aligned, or NULL */
     int32_t relu;
     float dropout_p;          /* in [0, 1); 0 disables dropout */
     uint64_t seed;
@@ -362,11 +362,14 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
  * once, Y written once as 16-byte stores).  `torch.mm(input, weight)` (pygcn/layers.py:33) and
  * the grad_input GEMM of its backward at bf16.  DEVICE pointers; rows 16-byte aligned; workspace
  * >= gcn_gemm_bf16_workspace_bytes(K, N) (0 = unsupported shape).
+ * epilogue: optional FORWARD epilogue, struct gcn_gemm_epilogue: bias fp32 [N], relu, dropout (
+ * applied to the fp32 accumulators before the rounding to bf16, the order of the SpMM epilogue);
+ * its backward-mask fields must be unset (GCN_E_BADARG).  NULL = plain product.
  */
 size_t gcn_gemm_bf16_workspace_bytes(int64_t K, int64_t N);
 int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, void *Y, int64_t ldy,
-                     int64_t M, int64_t K, int64_t N, void *workspace, size_t workspace_bytes,
-                     void *stream);
+                     int64_t M, int64_t K, int64_t N, const gcn_gemm_epilogue *epilogue,
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * out[256, 256] = Σ_{r < n_list} A[rows_a[r], :]ᵀ ⊗ G[rows_g[r], :]  — the weight gradient

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 19
+GCN_ABI_VERSION = 20
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -181,7 +181,8 @@ def lib():
     L.gcn_gemm_xw_bf16.restype = ctypes.c_int
     L.gcn_gemm_xw_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                                   ctypes.c_int64, ctypes.POINTER(GcnGemmEpilogue), ctypes.c_void_p,
+                                   ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_atg256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_atg256_workspace_bytes.argtypes = [ctypes.c_int64]
     L.gcn_gemm_atg256_f32.restype = ctypes.c_int

@@ -643,11 +643,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 // the W load), the X fragments of the NEXT tile are in flight while the current one is multiplied
 // and stored, and the bf16 output rows leave as 16-byte stores (the two half-waves exchange their
 // 4-column groups with v_permlane32_swap first).
-template <int K, int N>
+template <int K, int N, bool FWD_EPI>
 __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf16_kernel(const uint16_t *__restrict__ X, int64_t ldx,
                                                         const uint16_t *__restrict__ wimg,
                                                         uint16_t *__restrict__ Y, int64_t ldy,
-                                                        int64_t M, int64_t n_tiles)
+                                                        int64_t M, int64_t n_tiles, const H2Epi ep)
 {
     constexpr int KC = K / 16, NB = N / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];    // K * N * 2 bytes
@@ -701,6 +701,44 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
             for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
+                    if (FWD_EPI) {
+                        // the layer's forward epilogue on the fp32 accumulators (the layer evaluated
+                        // as (Â·X)·W + b, its last stage being this GEMM): bias, ReLU, Philox
+                        // dropout — the keep function of gcn_spmm.hip, per (row, 4 columns)
+#pragma unroll
+                        for (int gg = g; gg < g + 2; ++gg) {
+                            const int f = 32 * nb + 8 * gg + 4 * h;                // first of 4 columns
+                            float v[4] = {acc[nb][4 * gg], acc[nb][4 * gg + 1], acc[nb][4 * gg + 2],
+                                          acc[nb][4 * gg + 3]};
+                            if (ep.bias != nullptr) {
+                                const float *bq = ep.bias + 32 * nb + 8 * gg;     // (scalar loads)
+                                v[0] += h ? bq[4] : bq[0];
+                                v[1] += h ? bq[5] : bq[1];
+                                v[2] += h ? bq[6] : bq[2];
+                                v[3] += h ? bq[7] : bq[3];
+                            }
+                            if (ep.relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            }
+                            if (ep.drop_thresh != 0u) {                            // (uniform branch)
+                                uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
+                                if (ep.seed_dev != nullptr) {
+                                    const uint64_t sd = *ep.seed_dev;
+                                    k0 = (uint32_t)sd;
+                                    k1 = (uint32_t)(sd >> 32);
+                                }
+                                uint32_t r4[4];
+                                uint32_t cw = (uint32_t)(f >> 2);
+                                asm volatile("" : "+v"(cw));       // (no hoisting of the first round)
+                                h2_philox((uint32_t)row, (uint32_t)(row >> 32), cw, 0u, k0, k1, r4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = r4[j] >= ep.drop_thresh ? v[j] * ep.drop_scale : 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[nb][4 * gg + j] = v[j];
+                        }
+                    }
                     // groups k = 4nb + g and k + 1: this lane's 4 columns of each, packed to bf16
                     f32x2 p0 = {acc[nb][4 * g], acc[nb][4 * g + 1]}, p1 = {acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
                     f32x2 q0 = {acc[nb][4 * g + 4], acc[nb][4 * g + 5]}, q1 = {acc[nb][4 * g + 6], acc[nb][4 * g + 7]};
@@ -997,9 +1035,30 @@ size_t gcn_gemm_bf16_workspace_bytes(int64_t K, int64_t N)
 }
 
 int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, void *Y, int64_t ldy,
-                     int64_t M, int64_t K, int64_t N, void *workspace, size_t workspace_bytes,
-                     void *stream)
+                     int64_t M, int64_t K, int64_t N, const gcn_gemm_epilogue *epi, void *workspace,
+                     size_t workspace_bytes, void *stream)
 {
+    H2Epi ep = {};
+    if (epi != nullptr) {
+        if (!(epi->dropout_p >= 0.f) || epi->dropout_p >= 1.f)
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: dropout_p must be in [0, 1)");
+        if (epi->dropout_p > 0.f && !epi->relu)
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: dropout needs relu (out > 0 encodes the mask)");
+        if (epi->mask_src != nullptr)
+            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: no backward mask at bf16");
+        if (((uintptr_t)epi->bias) % 16 != 0)
+            return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: bias must be 16-byte aligned");
+        ep.bias = epi->bias;
+        ep.relu = epi->relu ? 1 : 0;
+        ep.drop_thresh = epi->dropout_p > 0.f
+                             ? (uint32_t)std::min(4294967295.0, (double)epi->dropout_p * 4294967296.0) : 0u;
+        if (epi->dropout_p > 0.f && ep.drop_thresh == 0u) ep.drop_thresh = 1u;
+        ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.seed_lo = (uint32_t)epi->seed;
+        ep.seed_hi = (uint32_t)(epi->seed >> 32);
+        ep.seed_dev = epi->seed_dev;
+    }
+    const bool fwd = ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u;
     const size_t need = gcn_gemm_bf16_workspace_bytes(K, N);
     if (need == 0)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: (K, N) must be (128,128), (128,256) or (256,128)");
@@ -1021,19 +1080,25 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
     // resident workgroups per CU: LDS (160 KiB / image) and registers allow 3 (128 x 128) … 1
     const int per_cu = need <= 32 * 1024 ? 3 : (need <= 64 * 1024 ? 2 : 1);
     const unsigned grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, (int64_t)256 * per_cu);
-#define GCN_LAUNCH_BF16(KK, NN)                                                                     \
+#define GCN_LAUNCH_BF16_E(KK, NN, EE)                                                               \
     do {                                                                                            \
-        hipError_t ae = hipFuncSetAttribute((const void *)gemm_bf16_kernel<KK, NN>,                \
+        hipError_t ae = hipFuncSetAttribute((const void *)gemm_bf16_kernel<KK, NN, EE>,            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); \
         if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw_bf16: LDS size"); \
-        hipLaunchKernelGGL((gemm_bf16_kernel<KK, NN>), dim3(grid), dim3(256), need, s,              \
+        hipLaunchKernelGGL((gemm_bf16_kernel<KK, NN, EE>), dim3(grid), dim3(256), need, s,          \
                            (const uint16_t *)X, ldx, (const uint16_t *)workspace, (uint16_t *)Y,   \
-                           ldy, M, tiles);                                                          \
+                           ldy, M, tiles, ep);                                                      \
+    } while (0)
+#define GCN_LAUNCH_BF16(KK, NN)                                                                     \
+    do {                                                                                            \
+        if (fwd) GCN_LAUNCH_BF16_E(KK, NN, true);                                                   \
+        else GCN_LAUNCH_BF16_E(KK, NN, false);                                                      \
     } while (0)
     if (K == 128 && N == 128) GCN_LAUNCH_BF16(128, 128);
     else if (K == 128 && N == 256) GCN_LAUNCH_BF16(128, 256);
     else GCN_LAUNCH_BF16(256, 128);
 #undef GCN_LAUNCH_BF16
+#undef GCN_LAUNCH_BF16_E
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw_bf16 launch");
     return 0;

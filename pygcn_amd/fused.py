@@ -139,23 +139,25 @@ class GCN2RowsFunction(torch.autograd.Function):
         # X is constant (cached), and |Â·B| <= ‖Â‖∞·max|B|
         bounded = x.dtype == torch.float32
         ctx.x_bound = _spmm.absmax_cached(x) if bounded else None
-        # Layer 1 REASSOCIATED when the GEMM kernel can carry the layer's epilogue (256 -> 256 fp32):
+        # Layer 1 REASSOCIATED when a GEMM kernel can carry the layer's epilogue (256 -> 256 fp32;
+        # bf16 128 -> 128 / 256):
         #     h1 = dropout(relu((Â·X)·W1 + b1))        instead of   dropout(relu(Â·(X·W1) + b1))
-        # — the same two kernels and the same bytes in the forward pass (an SpMM at width 256, a
-        # GEMM), but the product z = Â·X of THIS forward pass is then all the backward pass needs
-        # for grad_W1 = zᵀ·grad_pre1: no second sparse product for layer 1 (12.7 ms at C4).
-        ctx.reassoc = bool(bounded and _spmm._gemm_scheme == "h2" and tuple(w1.shape) == (256, 256)
-                           and x.shape[1] == 256 and x.stride(1) == 1
-                           and (b1 is None or (b1.dtype == torch.float32 and b1.is_contiguous())))
+        # — the same two kernels and the same bytes in the forward pass (an SpMM at the input's
+        # width, a GEMM), but the product z = Â·X of THIS forward pass is then all the backward
+        # pass needs for grad_W1 = zᵀ·grad_pre1: no second sparse product for layer 1 (12.7 ms at
+        # C4, 35.5 ms at C5).
+        ctx.reassoc = bool(_spmm.layer_gemm_reassociable(x, w1, b1))
         h1 = h_bound = z = None
+        ctx.z_bound = None
         if ctx.reassoc:
             z = spmm_csr(graph, x)
-            ctx.z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
-            h_bound = torch.zeros(1, dtype=torch.float32, device=x.device)   # max|h1|, exact
-            h1 = gemm_xw256(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, dropout_p=dropout_p,
-                            seed=seed)
+            if bounded:
+                ctx.z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
+                h_bound = torch.zeros(1, dtype=torch.float32, device=x.device)   # max|h1|, exact
+            h1 = _spmm.layer_gemm(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, dropout_p=dropout_p,
+                                  seed=seed)
             if h1 is None:                     # (alignment the kernel cannot take)
-                ctx.reassoc, z = False, None
+                ctx.reassoc, z, h_bound = False, None, None
         if h1 is None:
             s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
             sup1 = _dense_forward(x, w1, ctx.x_bound, s_max)

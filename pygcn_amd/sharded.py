@@ -608,16 +608,17 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         # GEMM of the halo rows disappears), and z_r = Â_r·[X_r ; X_halo] of this forward pass is all
         # the backward pass needs for grad_W (no local product in backward either).
         out = z = None
-        if (sg._hinted_product and x_local.is_cuda and x_local.dtype == torch.float32
-                and tuple(weight.shape) == (256, 256) and x_local.shape[1] == 256
-                and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
-            from .spmm import absmax_cached, gemm_xw256
+        from .spmm import absmax_cached, layer_gemm, layer_gemm_reassociable
+        if sg._hinted_product and x_local.is_cuda and layer_gemm_reassociable(x_local, weight, bias):
             z = sg._spmm(sg.A, x_local, tag="fwd_local", B2=x_halo)
             sg._toc(ev, "fwd")       # (the window of the product, as in the other branch)
             ev = None
-            xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
-                x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
-            out = gemm_xw256(z, weight, sg.A.inf_norm() * xb * 1.0001, bias=bias, relu=relu, **kw)
+            zb = None
+            if x_local.dtype == torch.float32:
+                xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
+                    x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
+                zb = sg.A.inf_norm() * xb * 1.0001
+            out = layer_gemm(z, weight, zb, bias=bias, relu=relu, **kw)
             if out is None:
                 z = None
         ctx.reassoc = out is not None

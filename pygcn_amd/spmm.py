@@ -426,10 +426,12 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     return Y
 
 
-def gemm_bf16(X, W):
+def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0):
     """X[M,K] · W[K,N] for bf16 storage through the streaming MFMA kernel (C-ABI gcn_gemm_xw_bf16;
-    (K, N) in {(128,128), (128,256), (256,128)} — config C5's layers are 128 -> 128).  None if the
-    operands do not fit (the caller then uses torch.mm)."""
+    (K, N) in {(128,128), (128,256), (256,128)} — config C5's layers are 128 -> 128).
+    `bias` / `relu` / `dropout_p` / `seed`: the layer's FORWARD epilogue on the fp32 accumulators
+    before the rounding to bf16 (same Philox keep function as the SpMM epilogue) — for a layer
+    evaluated as (Â·X)·W + b.  None if the operands do not fit (the caller then uses torch.mm)."""
     if (X.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not X.is_cuda or X.dim() != 2
             or W.dim() != 2 or X.shape[1] != W.shape[0] or X.shape[0] == 0 or X.stride(1) != 1
             or W.stride(1) != 1 or X.stride(0) % 8 or X.data_ptr() % 16):
@@ -439,14 +441,47 @@ def gemm_bf16(X, W):
     ws_bytes = L.gcn_gemm_bf16_workspace_bytes(K, N)
     if ws_bytes == 0:
         return None
+    ep = bias32 = None
+    if bias is not None or relu or dropout_p > 0.0:
+        if bias is not None:
+            if bias.numel() != N or bias.device != X.device:
+                return None
+            bias32 = bias.detach().to(torch.float32).contiguous()     # (kept alive past the launch)
+        seed_dev = None
+        if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
+            seed_dev, seed = seed.data_ptr(), 0
+        ep = _native.GcnGemmEpilogue(bias32.data_ptr() if bias32 is not None else None, int(bool(relu)),
+                                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev, None, 0, 1.0)
     Y = torch.empty((X.shape[0], N), dtype=torch.bfloat16, device=X.device)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     with torch.cuda.device(X.device):
         rc = L.gcn_gemm_xw_bf16(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), Y.data_ptr(),
-                                Y.stride(0), X.shape[0], K, N, ws.data_ptr(), ws_bytes,
+                                Y.stride(0), X.shape[0], K, N, ep, ws.data_ptr(), ws_bytes,
                                 torch.cuda.current_stream().cuda_stream)
     _native.check(rc, "gcn_gemm_xw_bf16")
     return Y
+
+
+def layer_gemm_reassociable(x, weight, bias):
+    """Can `epilogue((A·x)·W + b)` run with the epilogue in a hand-written GEMM's store?  fp32
+    256 -> 256 (gcn_gemm_xw256_f32_h2) or bf16 storage at the streaming kernel's shapes with
+    Fin <= Fout (the product A·x then is no wider than A·(x·W))."""
+    if x.dim() != 2 or not x.is_cuda or x.stride(1) != 1 or weight.dim() != 2 or x.dtype != weight.dtype:
+        return False
+    if x.dtype == torch.float32:
+        return (_gemm_scheme == "h2" and tuple(weight.shape) == (256, 256) and x.shape[1] == 256
+                and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())))
+    if x.dtype == torch.bfloat16:
+        return (tuple(weight.shape) in ((128, 128), (128, 256)) and x.shape[1] == weight.shape[0]
+                and weight.stride(1) == 1)
+    return False
+
+
+def layer_gemm(z, weight, z_bound=None, y_absmax=None, bias=None, relu=False, dropout_p=0.0, seed=0):
+    """epilogue(z·W + b) through the kernel layer_gemm_reassociable() promised (None if it declines)."""
+    if z.dtype == torch.float32:
+        return gemm_xw256(z, weight, z_bound, y_absmax, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
+    return gemm_bf16(z, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
 
 
 _identity_lists = {}
@@ -725,7 +760,7 @@ class GraphConvFunction(torch.autograd.Function):
         #  computed once and reused as the scaled GEMM's bound)
         x_bound = absmax_cached(input) if (input.dtype == torch.float32 and not input.requires_grad
                                            and input.is_cuda) else None
-        const_input = x_bound is not None
+        const_input = not input.requires_grad and input.is_cuda
         if x_bound is None and input.dtype == torch.float32 and input.is_cuda:
             x_bound = known_absmax(input)       # (left by the layer that produced this tensor)
         # REASSOCIATED for a constant input on the shape the GEMM kernel carries the epilogue for
@@ -734,17 +769,18 @@ class GraphConvFunction(torch.autograd.Function):
         # grad_W = zᵀ·grad_pre — no sparse product in backward (pygcn_amd/fused.py does the same
         # inside the one-node path).
         ctx.reassoc = False
-        if (const_input and _gemm_scheme == "h2" and not log_softmax and input.dim() == 2
-                and tuple(weight.shape) == (256, 256) and weight.dtype == torch.float32
-                and input.shape[1] == 256 and input.stride(1) == 1 and isinstance(graph, CSRGraph)
-                and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+        if (const_input and not log_softmax and isinstance(graph, CSRGraph)
+                and layer_gemm_reassociable(input, weight, bias)):
             z = spmm_csr(graph, input)
-            ctx.z_bound = graph.inf_norm() * x_bound * 1.0001
-            y_max = torch.zeros(1, dtype=torch.float32, device=input.device)
-            out = gemm_xw256(z, weight, ctx.z_bound, y_max, bias=bias, relu=relu, dropout_p=dropout_p,
+            ctx.z_bound = y_max = None
+            if x_bound is not None:
+                ctx.z_bound = graph.inf_norm() * x_bound * 1.0001
+                y_max = torch.zeros(1, dtype=torch.float32, device=input.device)
+            out = layer_gemm(z, weight, ctx.z_bound, y_max, bias=bias, relu=relu, dropout_p=dropout_p,
                              seed=seed)
             if out is not None:
-                remember_absmax(out, y_max)      # the next layer's GEMM scales by it
+                if y_max is not None:
+                    remember_absmax(out, y_max)      # the next layer's GEMM scales by it
                 ctx.reassoc = True
                 ctx.save_for_backward(z, weight, *([out] if relu else []))
                 return out
@@ -791,7 +827,8 @@ class GraphConvFunction(torch.autograd.Function):
             if grad_w is None:
                 grad_pre = grad_pre.contiguous()
                 grad_w = _weight_grad(z, grad_pre, ctx.z_bound,
-                                      torch.linalg.vector_norm(grad_pre, ord=float("inf")).reshape(1))
+                                      torch.linalg.vector_norm(grad_pre, ord=float("inf")).reshape(1)
+                                      if ctx.z_bound is not None else None)
             return None, grad_w, grad_bias, None, None, None, None, None
         c_flags = rows = None
         compact = sync_ok and hint is not None

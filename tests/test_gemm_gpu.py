@@ -303,3 +303,40 @@ def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p):
     a1 = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.25, seed=sd)
     a2 = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.25, seed=int(sd.item()))
     assert torch.equal(a1, a2)
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128)])
+@pytest.mark.parametrize("p", [0.0, 0.4])
+def test_bf16_gemm_forward_epilogue(dev, K, N, p):
+    """bias + ReLU + inverted dropout on the fp32 accumulators of the bf16 GEMM, rounded to bf16
+    once; the keep bits are those of the SpMM epilogue for the same (seed, row, column) — read off
+    an identity-adjacency product of an all-ones operand."""
+    from pygcn_amd import CSRGraph, spmm_csr
+    from pygcn_amd.spmm import gemm_bf16
+    gen = torch.Generator(device=dev).manual_seed(K + N)
+    M = 2777
+    X = torch.randn(M, K, generator=gen, device=dev).bfloat16()
+    W = (torch.randn(K, N, generator=gen, device=dev) * 0.2).bfloat16()
+    bias = torch.randn(N, generator=gen, device=dev).bfloat16()
+    seed = 0x0BAD_5EED_1234_5678
+    got = gemm_bf16(X, W, bias=bias, relu=True, dropout_p=p, seed=seed)
+    assert got is not None and got.dtype == torch.bfloat16 and got.shape == (M, N)
+    pre = (X.double() @ W.double() + bias.double()).clamp_min(0)
+    keep = torch.ones(M, N, dtype=torch.bool, device=dev)
+    if p > 0:
+        ident = CSRGraph(torch.arange(M + 1, device=dev, dtype=torch.int32),
+                         torch.arange(M, device=dev, dtype=torch.int32), torch.ones(M, device=dev), (M, M))
+        keep = spmm_csr(ident, torch.ones(M, N, device=dev).bfloat16(), relu=True, dropout_p=p, seed=seed) != 0
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+    want = torch.where(keep, pre / (1 - p), torch.zeros_like(pre))
+    err = (got.double() - want).abs()
+    assert bool((err <= 2.0 ** -8 * want.abs() + 1e-5 * float(want.abs().max())).all())
+    clear = pre > 1e-3 * float(pre.max())                   # (away from the ReLU's rounding edge)
+    assert torch.equal((got != 0) & clear, keep & clear)
+    assert torch.equal(got, gemm_bf16(X, W, bias=bias, relu=True, dropout_p=p, seed=seed))
+    if p > 0:
+        assert not torch.equal(got, gemm_bf16(X, W, bias=bias, relu=True, dropout_p=p, seed=seed + 1))
+    # bias only
+    b_only = gemm_bf16(X, W, bias=bias)
+    ref = X.double() @ W.double() + bias.double()
+    assert bool(((b_only.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5 * float(ref.abs().max())).all())
