@@ -116,6 +116,69 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, exchange, build):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _bf16_worker(rank, world, port, n, n_edges, out_dir):
+    """Config C5's storage (bf16, F = 128) through the sharded path: two ranks on one GPU against
+    the single-GPU HIP model on the same bf16 parameters and inputs.  Both run bf16 pipelines with
+    one rounding per stage; they differ by summation order and by the ranks' split of the
+    gradient sums, so the comparison is at bf16 resolution."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.sharded import ShardedGCN, ShardedGraph
+    from pygcn_amd.utils import rmat_graph
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pygcn_amd._rehearsal import install_host_staging
+    install_host_staging()
+    try:
+        dev = torch.device("cuda:0")
+        F = 128
+        sg = ShardedGraph.from_rmat(n, n_edges, rank, world, dev, seed=7, exchange="halo")
+        rowptr, col, val = rmat_graph(n, n_edges, seed=7, device=dev)
+        x = torch.from_numpy(np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)).bfloat16()
+        labels = torch.from_numpy(np.random.default_rng(4).integers(0, F, n))
+        torch.manual_seed(7)
+        model = GCN(F, F, F, dropout=0.0).to(dev).bfloat16()
+        smodel = ShardedGCN(model, sg)
+        model.train()
+        seen = []
+        import pygcn_amd.spmm as S
+        orig = S.layer_gemm
+        S.layer_gemm = lambda *a, **k: (seen.append(a[0].dtype), orig(*a, **k))[1]
+        try:
+            logp = smodel(x[sg.r0:sg.r1].to(dev), sg)
+        finally:
+            S.layer_gemm = orig
+        assert seen == [torch.bfloat16]          # the first layer took the reassociated branch
+        loss = smodel.nll_loss(logp.float(), labels[sg.r0:sg.r1].to(dev))
+        loss.backward()
+        smodel.allreduce_grads()
+        torch.manual_seed(7)
+        ref = GCN(F, F, F, dropout=0.0).to(dev).bfloat16()
+        ref.train()
+        rl = ref(x.to(dev), CSRGraph(rowptr, col, val, (n, n)))
+        rloss = torch.nn.functional.nll_loss(rl.float(), labels.to(dev))
+        rloss.backward()
+
+        def close(a, b, what, rel):
+            err = (a.double() - b.double()).abs().max().item()
+            scale = b.double().abs().max().item()
+            assert err <= rel * scale, f"rank {rank}: {what} {err:.3e} vs scale {scale:.3e}"
+        close(logp, rl[sg.r0:sg.r1], "logp block", 2.0 ** -6)
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+            close(p.grad, q.grad, k + ".grad", 2.0 ** -4)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_bf16_storage(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_bf16_worker, args=(2, _free_port(), 40000, 400000, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 def _nccl_worker(rank, world, port, n, n_edges, out_dir):
     """The sharded path on the REAL backend (RCCL), world size 1 — the only RCCL execution a
     one-GPU box allows: communicator init bound to the device, all_gather_into_tensor (degree
