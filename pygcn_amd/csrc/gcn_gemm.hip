@@ -381,8 +381,11 @@ __device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2,
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // (one 32 x 32 -> 64 multiply per product — v_mad_u64_u32 — instead of a mul_hi + mul_lo
+        //  pair: integer multiplies run at a quarter of the VALU rate and dominate the epilogue)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
