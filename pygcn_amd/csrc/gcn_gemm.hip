@@ -1,37 +1,37 @@
-// gcn_gemm.hip — Y[M,256] = X[M,256] · W[256,256] for the dense half of GraphConvolution
-// (reference pygcn/layers.py:33 `support = torch.mm(input, self.weight)` and the grad_input GEMM
-// of its backward), written for gfx950 MFMA.  SURVEY §8 row f2.
+// gcn_gemm.hip — the dense half of GraphConvolution on gfx950 MFMA:
+// `support = torch.mm(input, self.weight)` (reference pygcn/layers.py:33) and the two GEMMs of its
+// backward, at the layer shapes of configs C3–C5.  Four kernels:
 //
-// fp32 in, fp32 out, fp32 accumulate.  gfx950 has no reduced-precision fp32 MFMA (no xf32), and
-// the exact fp32 MFMA runs at 1/16 of the bf16 rate, so each fp32 operand is split on the fly into
-// three bf16 parts x = h + m + l (8 + 8 + 8 significant bits = the 24 of fp32) and the product is
-// formed from the six partial products that matter:
-//     x·w ≈ h·h' + h·m' + m·h' + h·l' + l·h' + m·m'        (dropped terms <= 2^-24 relative)
-// = 6 bf16 MFMAs instead of 16 bf16-equivalents of one fp32 MFMA, with fp32-level accuracy
-// (checked against an fp64 product in tests/test_gemm_gpu.py).
+//   gemm_xw256_h2_kernel   Y[M,256] = X[M,256]·W[256,256], fp32 in / out (the default).  gfx950 has
+//                          no reduced-precision fp32 MFMA and the exact one runs at 1/16 of the
+//                          16-bit rate, so both operands are scaled by exact powers of two and
+//                          split into TWO fp16 parts: x·w ≈ h·h' + h·m' + m·h', three MFMAs per
+//                          product, ~4e-7 normwise against fp64.  Optional row list on the input,
+//                          the layer's forward epilogue (bias, ReLU, Philox dropout) or the
+//                          ReLU/dropout backward mask in the store, max|Y| as a side result.
+//   gemm_xw256_kernel      the same product from three bf16 parts (six MFMAs, no scaling) — round
+//                          1's kernel, kept as the scheme that needs no bound of max|X|.
+//   gemm_atg256_h2_kernel  grad_W[256,256] = Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] over a row LIST (+ ordered
+//                          slab reduction), the weight gradient without compacting copies.
+//   gemm_bf16_kernel<K,N>  bf16 storage (config C5: 128 -> 128), W resident in LDS, streaming.
 //
-// Structure: a 512-thread workgroup owns 256 rows; each of its 8 waves owns 32 rows x all 256
-// columns (8 accumulator tiles of 32x32 = 128 VGPRs, held TRANSPOSED so a lane owns an output row
-// and stores 16 bytes at a time).  The K loop (16 steps of 16) is fully unrolled.  Per step a wave
-// multiplies its pre-split X fragment with the pre-split W chunk (3 x 8 KiB, fragment-ordered,
-// conflict-free) that the workgroup staged in LDS: two steps of W per barrier, double-buffered;
-// W fragments of column block nb+1 are read while the MFMAs of block nb run (two register sets);
-// the X fragment comes straight from global memory in MFMA layout (8 consecutive floats per lane,
-// fetched two steps ahead) and is split BEHIND the previous step's MFMA run (pinned there by an
+// Structure of the fp32 product kernels: a 512-thread workgroup owns 256 rows; each of its 8 waves
+// owns 32 rows x all 256 columns (8 accumulator tiles of 32x32 = 128 VGPRs, held TRANSPOSED so a
+// lane owns an output row and stores 16 bytes at a time).  The K loop (16 steps of 16) is fully
+// unrolled.  Per step a wave multiplies its pre-split X fragment with the pre-split W chunk
+// (fragment-ordered, conflict-free) that the workgroup staged in LDS: two steps of W per barrier,
+// double-buffered; W fragments of column block nb+1 are read while the MFMAs of block nb run; the
+// X fragment comes straight from global memory in MFMA layout (8 consecutive floats per lane,
+// fetched three steps ahead) and is split BEHIND the previous step's MFMA run (pinned there by an
 // opaque asm, or hipcc sinks it back to just after the barrier, where it idles the pipe).  W is
-// split and fragment-ordered once per call by a small prep kernel into a 384 KiB workspace.
+// split and fragment-ordered once per call by a small prep kernel into the workspace.
 //
-// Measured on MI355X at M = 10^7 (tools/gemm_custom_probe.py, same box): 7.6 ms against 10.0 ms
-// for hipBLASLt's fp32 MFMA kernel (first version 8.0 ms); error against an fp64 product 6e-7
-// normwise (hipBLASLt fp32: 7e-7).  Ablations on the first version: the MFMA + LDS-read core alone
-// 5.1 ms (the chip lowers its clock in MFMA-dense loops: 1.91 GHz), stores +0.7 ms, W staging +
-// barrier +1.1 ms, X loads +1.3 ms.  Counters (profiles/r01_gemm_pmc.md): MFMA pipe busy 49 %.
-// Steps that paid: s_setprio around the MFMA run (4 %), split behind the MFMA run + B-fragment
-// double buffering (4 %), two steps per barrier (2 %).  Tried without gain: X staged through
-// wave-private LDS in full 128-B lines, 4-wave workgroups, a deeper X ring, persistent workgroups
-// with cross-tile prefetch (spills at 256 VGPRs), storing each column block under the MFMAs of
-// the next one in the last K step (7.63 vs 7.62 ms).  Next would be the guide's multi-phase schedule
-// (LDS-DMA for the W stream, staggered wave halves).
+// Measured on MI355X at M = 10^7 (one process, interleaved): h2 5.2 ms (persistent workgroups with
+// a cross-tile pipeline), three bf16 parts 7.5 ms, hipBLASLt fp32 9.95 ms.  The h2 kernel is
+// bound by the CU's vector-memory instruction issue (3e7 wave-level loads / stores of 1 KiB per
+// launch, already 16 B per lane), not by MFMA (37 % busy) or HBM (3.9 TB/s): DESIGN §3.7, with the
+// variants that were measured and rejected in §7 (resident-W column split, stores through LDS,
+// 4-wave workgroups, row pitch, X staged through LDS in full lines, a deeper X ring).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
