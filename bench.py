@@ -547,9 +547,11 @@ def main():
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
-            "spmm_bwd_note": ("layer 2: transpose product restricted to the operand rows idx_train (5 % "
-                              "of the rows) and to the output rows that have a neighbour in idx_train "
-                              "(16 %); layer 1 (input needs no gradient) is evaluated as (A x X) x W1, "
+            "spmm_bwd_note": ("layer 2: the transpose product on the block of A^T with columns idx_train "
+                              "(5 % of the rows: the only non-zero rows of the operand) and rows = the "
+                              "vertices that have a neighbour in idx_train (16 %: the only rows of the "
+                              "result that can be non-zero), cut once per (graph, idx_train), compact "
+                              "operand in, compact result out; layer 1 (input needs no gradient) is evaluated as (A x X) x W1, "
                               "so grad_W1 = (A x X)^T x grad_pre reuses the A x X of the SAME step's "
                               "forward pass and needs no sparse product in backward (0 ms); `value` "
                               "and `roofline` are the unrestricted forward products; the "

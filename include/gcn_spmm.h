@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 20
+#define GCN_ABI_VERSION 21
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -348,6 +348,9 @@ typedef struct gcn_gemm_epilogue {
     const float *mask_src;    /* DEVICE fp32 [*, 256] (leading dimension ld_mask) or NULL */
     int64_t ld_mask;
     float mask_scale;
+    /* optional DEVICE int32 list [M]: output row r reads mask row mask_rows[r]; NULL = the input
+     * row (x_rows[r], or r).  For a COMPACT input whose rows belong to listed rows of a full mask. */
+    const int32_t *mask_rows;
 } gcn_gemm_epilogue;
 
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 20
+GCN_ABI_VERSION = 21
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -52,7 +52,7 @@ class GcnGemmEpilogue(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32), ("dropout_p", ctypes.c_float),
                 ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p),
                 ("mask_src", ctypes.c_void_p), ("ld_mask", ctypes.c_int64),
-                ("mask_scale", ctypes.c_float)]
+                ("mask_scale", ctypes.c_float), ("mask_rows", ctypes.c_void_p)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)

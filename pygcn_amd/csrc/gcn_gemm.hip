@@ -371,6 +371,7 @@ struct H2Epi {
     const uint64_t *seed_dev;   // optional: the seed as of execution time (hipGraph replays)
     const float *mask_src;      // optional backward mask: y = mask_src > 0 ? y * mask_scale : 0
     int64_t ld_mask;
+    const int32_t *mask_rows;   // optional: mask row of output row r (default: its input row)
     float mask_scale;
 };
 
@@ -562,7 +563,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         if (row_ok) {
             float *yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
-            const float *mrow = mask_src ? mask_src + src_row * ld_mask + 4 * (lane >> 5) : nullptr;
+            const float *mrow = mask_src
+                ? mask_src + (ep.mask_rows ? (int64_t)ep.mask_rows[row] : src_row) * ld_mask + 4 * (lane >> 5)
+                : nullptr;
             const float *bias_p = ep.bias;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
@@ -997,6 +1000,7 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
         ep.seed_dev = epi->seed_dev;
         ep.mask_src = mask_src;
         ep.ld_mask = ld_mask;
+        ep.mask_rows = mask_src != nullptr ? epi->mask_rows : nullptr;
         ep.mask_scale = epi->mask_scale;
     }
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)

@@ -17,11 +17,11 @@ every later gradient CAN be non-zero follows from the graph alone:
                  as (Â·X)·W1 — 256 -> 256 fp32 — so layer 1 needs no sparse product in backward)
 
 `model(features, adj, rows=idx_train)` returns `output[idx_train]` from a node that keeps all of
-this inside: R2 is computed once per (graph, rows) from the CSR structure, every intermediate
-gradient lives in COMPACT form ([|R|, C] and [|R2|, H] tensors), the two sparse products are the
-row-restricted launches of the HIP kernel (operand-row hint + output-row selection,
-`gcn_epilogue.b_row_nonzero / c_row_select`), and nothing of size [N, ·] is zero-filled,
-scattered into, or swept to find its non-zero rows.  Compared with letting the dense
+this inside: R2 and the block of Âᵀ with rows R2 and columns R are cut once per (graph, rows) from
+the CSR structure, every intermediate gradient lives in COMPACT form ([|R|, C] and [|R2|, H]
+tensors), the layer-2 transpose product is the HIP kernel on that block (layer 1 needs none, see
+below; other widths use the row-restricted launch, `gcn_epilogue.c_row_select`), and nothing of
+size [N, ·] is allocated, zero-filled, scattered into, or swept to find its non-zero rows.  Compared with letting the dense
 `grad_output [N, C]` travel through autograd this removes per epoch at config C4: the 10 GB zero
 fill of index_put's backward and its scatter, the NLL kernels over [N, C], two full-height
 backward sweeps and the scatter of grad_h1 — ≈ 11 ms of an 84 ms epoch — and every host
@@ -48,9 +48,9 @@ def _maybe_poisoned(shape, dtype, device):      # (reads the test switch at call
 
 class RowSets:
     """What the backward pass needs to know about the loss rows R, computed ONCE per
-    (graph, rows tensor): R sorted and unique, its bitmap / count (operand hint of Âᵀ·grad_pre2),
-    R2 = the columns that occur in rows R of Â (= the rows of Âᵀ·grad_pre2 that can be non-zero)
-    with its bitmap / count (output-row selection of both restricted products)."""
+    (graph, rows tensor): R sorted and unique, R2 = the columns that occur in rows R of Â (= the
+    rows of Âᵀ·grad_pre2 that can be non-zero) with its bitmap / count, and `at_block` = the
+    [|R2|, |R|] block of Âᵀ the layer-2 backward product runs on."""
 
     def __init__(self, graph, rows):
         dev, n = graph.device, graph.shape[0]
@@ -61,23 +61,29 @@ class RowSets:
         self.rows_u, self.inverse = torch.unique(rows, return_inverse=True)      # sorted
         self.has_duplicates = self.rows_u.numel() != rows.numel()
         self.n_u = int(self.rows_u.numel())
-        # upstream's idx_train is a range (utils.py:370 `range(140)`): rows r0, r0+1, … in order.
-        # The loss gradient is then written straight into its rows of the [N, C] operand buffer.
-        self.range_start = None
-        if self.n_u and not self.has_duplicates:
-            r0 = int(rows[0])
-            if bool((rows == torch.arange(r0, r0 + self.n_u, device=dev)).all()):
-                self.range_start = r0
-        mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        mask[self.rows_u] = True
-        self.hint = pack_row_flags(mask)                                         # (bitmap, count)
         rp = graph.rowptr.to(torch.int64)
         starts, lens = rp[self.rows_u], rp[self.rows_u + 1] - rp[self.rows_u]
         total = int(lens.sum())
         idx = torch.repeat_interleave(starts - torch.cumsum(lens, 0) + lens, lens) + \
             torch.arange(total, device=dev)
-        self.rows2 = torch.unique(graph.col[idx].to(torch.int64))                # sorted
+        cols = graph.col[idx].to(torch.int64)
+        self.rows2 = torch.unique(cols)                                          # sorted
         self.n2 = int(self.rows2.numel())
+        # The block of Âᵀ the backward product needs — rows R2, columns R — as its own small CSR
+        # (compact row / column numbering): entry (r, c) of Â with r in R becomes entry
+        # (pos of c in R2, pos of r in R) of the block.  Sorted by (row, source row): within a row
+        # the entries come in the order of the full CSR(Âᵀ).  Built once per (graph, rows).
+        src = torch.repeat_interleave(torch.arange(self.n_u, device=dev, dtype=torch.int64), lens)
+        dst = torch.searchsorted(self.rows2, cols)
+        order = torch.argsort(dst * max(self.n_u, 1) + src)
+        rp = torch.zeros(self.n2 + 1, dtype=torch.int64, device=dev)
+        if total:
+            torch.cumsum(torch.bincount(dst, minlength=self.n2), 0, out=rp[1:])
+        self.at_block = CSRGraph(rp.to(torch.int32 if total < 2 ** 31 - 1 else torch.int64),
+                                 src[order].to(torch.int32), graph.val[idx][order].contiguous(),
+                                 (self.n2, self.n_u))
+        self.sorted_unique = bool(self.n_u == rows.numel() and (self.n_u == 0 or bool(
+            (rows == self.rows_u).all())))
         self.rows2_i32 = self.rows2.to(torch.int32)
         self.rows2_padded = _spmm.padded_row_list(self.rows2)     # (for the weight-gradient kernel)
         mask2 = torch.zeros(graph.shape[1], dtype=torch.bool, device=dev)
@@ -188,13 +194,7 @@ class GCN2RowsFunction(torch.autograd.Function):
         graph_t = graph.t()
         # ---- loss rows: log_softmax backward on the compact [|R|, C] tensors — one HIP pass
         # (gcn_log_softmax_backward_colsum: grad_pre and the bias gradient's column sums together)
-        grad_pre2 = None
-        if rs.range_start is not None and grad_rows.dtype == dt:
-            # rows R are a range: the kernel writes grad_pre2's rows where the product reads them
-            grad_pre2 = _operand_buffer(n, grad_rows.shape[1], dt, dev, None, None, rs.n_u)
-        one_pass = _spmm.backward_with_colsum(
-            grad_rows.contiguous(), out_rows, log_softmax=True,
-            dest=None if grad_pre2 is None else grad_pre2[rs.range_start:rs.range_start + rs.n_u]) \
+        one_pass = _spmm.backward_with_colsum(grad_rows.contiguous(), out_rows, log_softmax=True) \
             if (grad_rows.dtype == out_rows.dtype and not rs.has_duplicates) else None
         if one_pass is not None:
             gp, colsum, _ = one_pass
@@ -203,48 +203,45 @@ class GCN2RowsFunction(torch.autograd.Function):
             g = grad_rows.float()
             gp = g - out_rows.float().exp() * g.sum(1, keepdim=True)
             grad_b2 = gp.sum(0).to(ctx.bias_dtypes[1]) if (ctx.has_bias[1] and need_b2) else None
-        dst_rows = rs.rows_user                            # where the rows of gp belong in [N, C]
-        if rs.has_duplicates:                              # the same vertex listed twice: add up
-            gp = torch.zeros((rs.n_u, gp.shape[1]), dtype=gp.dtype, device=dev).index_add_(
-                0, rs.inverse, gp)
-            dst_rows = rs.rows_u
         gp = gp.to(dt)
+        if rs.has_duplicates:                              # the same vertex listed twice: add up
+            gp = torch.zeros((rs.n_u, gp.shape[1]), dtype=dt, device=dev).index_add_(0, rs.inverse, gp)
+        elif not rs.sorted_unique:                         # rows of R in sorted order (the block's columns)
+            gp = torch.empty_like(gp).index_copy_(0, rs.inverse, gp)
         grad_w1 = grad_w2 = grad_b1 = grad_x = None
         if not (need_x or need_w1 or need_b1 or need_w2):
             return grad_x, grad_w1, grad_b1, grad_w2, grad_b2, None, None, None, None, None
-        # ---- layer 2: Âᵀ · grad_pre2 restricted to operand rows R and output rows R2
-        if grad_pre2 is None or one_pass is None:
-            grad_pre2 = _operand_buffer(n, gp.shape[1], dt, dev, dst_rows, gp, rs.n_u)
-        grad_sup2 = spmm_csr(graph_t, grad_pre2, tag="bwd_l2", b_hint=rs.hint, c_select=rs.hint2[0],
-                             out=_maybe_poisoned((n, gp.shape[1]), dt, dev))
+        # ---- layer 2: Âᵀ · grad_pre2 — only rows R of grad_pre2 are non-zero and only rows R2 of
+        # the result can be: the product runs on that block of Âᵀ (RowSets.at_block), compact
+        # operand [|R|, C] in, compact result [|R2|, C] out; nothing of size [N, C] exists
+        grad_sup2 = spmm_csr(rs.at_block, gp.contiguous(), tag="bwd_l2")
         # |Âᵀ·grad_pre2| <= ‖Âᵀ‖∞ · max|grad_pre2|  (max over the small [|R|, C] tensor)
         f32 = dt == torch.float32
         gs_bound = graph_t.inf_norm() * torch.linalg.vector_norm(gp, ord=float("inf")) * 1.0001 \
             if f32 else None
-        # the GEMMs read the rows R2 of grad_sup2 / h1 in place (row lists), no compacting copies;
-        # the ReLU / dropout mask (h1 > 0 encodes ReLU and keep) is applied in the GEMM's store
+        # h1 is read at the rows R2 in place (row lists), no compacting copy; the ReLU / dropout
+        # mask (h1 > 0 encodes ReLU and keep) is applied in the GEMM's store
         fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
-        gs2 = h1c = None
+        h1c = None
         if need_w2:
-            grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, rs.rows2_padded,
+            grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, None,
                                              ctx.h_bound, gs_bound, n_list=rs.n2) if fast else None
             if grad_w2 is None:
-                gs2, h1c = grad_sup2.index_select(0, rs.rows2), h1.index_select(0, rs.rows2)
-                grad_w2 = _weight_grad(h1c, gs2)
+                h1c = h1.index_select(0, rs.rows2)
+                grad_w2 = _weight_grad(h1c, grad_sup2)
         gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
         w2t = w2.t().contiguous()
-        gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, rows=rs.rows2_i32, mask_src=h1,
+        gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_rows=rs.rows2_i32,
                            mask_scale=ctx.scale) if fast else None
         if gpre1 is None:
-            gs2 = grad_sup2.index_select(0, rs.rows2) if gs2 is None else gs2
             h1c = h1.index_select(0, rs.rows2) if h1c is None else h1c
-            gh1 = _dense_forward(gs2, w2t, gs_bound, gh_max)
+            gh1 = _dense_forward(grad_sup2, w2t, gs_bound, gh_max)
             gpre1 = torch.where(h1c > 0, gh1 * ctx.scale if ctx.scale != 1.0 else gh1,
                                 torch.zeros((), dtype=dt, device=dev))
             if gh_max is not None:
                 gh_max = gh_max * ctx.scale
             del gh1
-        del gs2, h1c, grad_pre2, grad_sup2
+        del h1c, grad_sup2
         if ctx.has_bias[0] and need_b1:
             sums = _spmm.backward_with_colsum(gpre1) if gpre1.is_contiguous() else None   # (one HIP pass)
             grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])

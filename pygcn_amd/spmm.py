@@ -155,8 +155,7 @@ def relu_dropout_backward(grad_out, out, scale=1.0):
     return res
 
 
-def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_zero_rows=False,
-                         dest=None):
+def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_zero_rows=False):
     """(grad_pre, column sums of grad_pre, row-sparsity hint) in ONE pass over fp32 / bf16 [N, F]
     tensors (C-ABI gcn_relu_dropout_backward_colsum); `out=None`: no masking, grad_pre is grad_out.
     `log_softmax=True`: `out` holds log-probabilities and grad_pre = grad_out - exp(out) *
@@ -166,8 +165,6 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_
     `skip_zero_rows=True` (needs `out` and a hint): rows of grad_pre that are entirely zero are
     NOT written — only the rows whose hint bit is set are defined; for consumers that read those
     rows only.
-    `dest` (needs `out`): a contiguous tensor of grad_out's shape and dtype that receives grad_pre
-    (e.g. a row range of a larger operand buffer) instead of a fresh one.
     Returns None when the shape/dtype is outside the kernel's envelope (caller falls back to
     relu_dropout_backward + torch's sum)."""
     _require_cuda(grad_out, "grad_out")
@@ -182,11 +179,8 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_
                                  or grad_out.shape[1] // (16 // grad_out.element_size()) > 64))):
         return None
     n, F = grad_out.shape
-    if dest is not None and (out is None or dest.shape != grad_out.shape or dest.dtype != grad_out.dtype
-                             or dest.device != grad_out.device or not dest.is_contiguous()):
-        raise RuntimeError("backward_with_colsum: dest must be a contiguous tensor like grad_out (and needs out)")
-    grad_pre = dest if dest is not None else (
-        _maybe_poisoned(grad_out.shape, grad_out.dtype, grad_out.device) if out is not None else grad_out)
+    grad_pre = _maybe_poisoned(grad_out.shape, grad_out.dtype, grad_out.device) if out is not None \
+        else grad_out
     colsum = torch.empty(F, dtype=torch.float32, device=grad_out.device)
     hint = None
     if F <= (256 if grad_out.dtype == torch.float32 else 512):   # a row lives inside one wavefront
@@ -343,7 +337,7 @@ class SpMMFunction(torch.autograd.Function):
 
 
 def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0,
-               bias=None, relu=False, dropout_p=0.0, seed=0):
+               bias=None, relu=False, dropout_p=0.0, seed=0, mask_rows=None):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -354,7 +348,8 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     tensor [1], zeroed by the caller) receives max|Y|, from which a layer derives the next bound
     without a pass over the data.  `rows` (int32 device list): output row r is the product of
     input row rows[r] — a gather fused into the kernel's loads.  `mask_src` ([*, 256] fp32, read
-    at the same input rows): the store becomes mask_src > 0 ? y * mask_scale : 0, the backward of a
+    at the same input rows, or — `mask_rows`, an int32 device list — at mask_rows[r] for output
+    row r): the store becomes mask_src > 0 ? y * mask_scale : 0, the backward of a
     fused ReLU / dropout epilogue, in the GEMM's own store (None if it cannot be fused).
     `bias` / `relu` / `dropout_p` / `seed`: FORWARD epilogue in the store, y = dropout(relu(acc +
     bias)) with the same Philox keep function as the SpMM epilogue — for a layer evaluated as
@@ -377,6 +372,10 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                                  or mask_src.stride(1) != 1 or mask_src.stride(0) % 4
                                  or mask_src.data_ptr() % 16 or mask_src.device != X.device):
         return None
+    if mask_rows is not None and (mask_rows.dtype != torch.int32 or not mask_rows.is_contiguous()
+                                  or mask_rows.device != X.device
+                                  or mask_rows.numel() < (rows.numel() if rows is not None else X.shape[0])):
+        raise RuntimeError("gemm_xw256: mask_rows must be a contiguous int32 device list, one entry per output row")
     if rows is not None:
         if _gemm_scheme != "h2":
             X, rows = X.index_select(0, rows.long()), None
@@ -407,7 +406,8 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                     bias.detach().data_ptr() if bias is not None else None, int(bool(relu)),
                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
                     mask_src.data_ptr() if mask_src is not None else None,
-                    mask_src.stride(0) if mask_src is not None else 0, float(mask_scale))
+                    mask_src.stride(0) if mask_src is not None else 0, float(mask_scale),
+                    mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None)
             rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0),
                                          rows.data_ptr() if rows is not None else None,
                                          W.data_ptr(), W.stride(0),
@@ -451,7 +451,7 @@ def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0):
         if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
             seed_dev, seed = seed.data_ptr(), 0
         ep = _native.GcnGemmEpilogue(bias32.data_ptr() if bias32 is not None else None, int(bool(relu)),
-                                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev, None, 0, 1.0)
+                                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev, None, 0, 1.0, None)
     Y = torch.empty((X.shape[0], N), dtype=torch.bfloat16, device=X.device)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     with torch.cuda.device(X.device):

@@ -93,8 +93,8 @@ def test_rmat_step_matches_oracle(oracle, dev, poison, fin, hid, ncls, share):
 
 @pytest.mark.parametrize("start,count", [(0, 1500), (1234, 4000), (29000, 1000)])
 def test_loss_rows_that_are_a_range(oracle, dev, poison, start, count):
-    """upstream's idx_train is `range(140)` (utils.py:370): for a range the log_softmax backward
-    writes the loss gradient straight into its rows of the [N, C] operand (no compact copy)."""
+    """upstream's idx_train is `range(140)` (utils.py:370): a range at the start, in the middle and
+    at the end of the vertex list (the block of Âᵀ the backward product runs on is cut per row set)."""
     from pygcn_amd import GCN, CSRGraph, fused
     from pygcn_amd.utils import rmat_graph
     n = 30000
@@ -104,7 +104,8 @@ def test_loss_rows_that_are_a_range(oracle, dev, poison, start, count):
     x = torch.from_numpy(gin.dense((n, 256), 6)).to(dev)
     labels = np.random.default_rng(start).integers(0, 256, n)
     idx = np.arange(start, start + count)
-    assert fused.row_sets(g, torch.from_numpy(idx).to(dev)).range_start == start
+    rs = fused.row_sets(g, torch.from_numpy(idx).to(dev))
+    assert rs.sorted_unique and rs.at_block.shape == (rs.n2, count)
     torch.manual_seed(2)
     model = GCN(256, 256, 256, dropout=0.0).to(dev)
     _check(model, x, g, a, labels, idx, oracle)
