@@ -82,3 +82,63 @@ def test_sampled_rows_against_oracle(c4, oracle):
     ref = oracle.spmm_csr(rp.cpu().numpy(), inv.cpu().numpy().astype(np.int32),
                           vals.cpu().numpy(), B[ucols].cpu().numpy())
     assert_normwise(out[rows].cpu(), ref, 1e-5, "sampled rows incl. hubs")
+
+
+def test_transpose_block_equals_the_full_transpose_product(c4):
+    """The [|R2|, |R|] block of Âᵀ the one-node backward pass multiplies (cut from the rows R of
+    CSR(Â)) against the full cached CSR(Âᵀ) on an operand that is zero outside R: the same rows,
+    and nothing outside R2."""
+    from pygcn_amd import fused, spmm_csr
+    g, n = c4
+    dev = g.device
+    rows = torch.arange(n * 140 // 2708, device=dev)                 # the bench's idx_train share
+    rs = fused.row_sets(g, rows)
+    assert rs.at_block.shape == (rs.n2, rs.n_u) and rs.n_u == rows.numel()
+    gen = torch.Generator(device=dev).manual_seed(11)
+    gp = torch.randn(rs.n_u, 256, generator=gen, device=dev)
+    small = spmm_csr(rs.at_block, gp)
+    operand = torch.zeros(n, 256, device=dev)
+    operand[rows] = gp
+    full = spmm_csr(g.t(), operand)
+    del operand
+    scale = float(full.abs().max())
+    assert float((full.index_select(0, rs.rows2) - small).abs().max()) <= 1e-5 * scale
+    outside = torch.ones(n, dtype=torch.bool, device=dev)
+    outside[rs.rows2] = False
+    assert float(full[outside].abs().max()) == 0.0                   # R2 is exactly where it can be non-zero
+
+
+def test_training_step_routes_agree(c4):
+    """One training step of the 2-layer model at C4 by two routes through the HIP kernels:
+    `model(x, adj, rows=idx)` (one autograd node: transpose block, gather-fused weight gradients,
+    masks in the GEMM stores) and upstream's unchanged lines `model(x, adj)[idx]` (one node per
+    layer: dense gradient through autograd, row bitmaps found at run time, row-restricted
+    launches).  Same forward kernels, different backward routes: loss, selected rows and all four
+    parameter gradients must agree."""
+    from pygcn_amd import GCN
+    g, n = c4
+    dev = g.device
+    gen = torch.Generator(device=dev).manual_seed(44)
+    x = torch.randn(n, 256, generator=gen, device=dev)
+    labels = torch.randint(0, 256, (n,), generator=gen, device=dev)
+    idx = torch.arange(n * 140 // 2708, device=dev)
+    torch.manual_seed(42)
+    model = GCN(256, 256, 256, dropout=0.0).to(dev)
+    model.train()
+    out_rows = model(x, g, rows=idx)
+    loss = torch.nn.functional.nll_loss(out_rows, labels[idx])
+    loss.backward()
+    fused_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    sel = out_rows.detach().clone()
+    model.zero_grad(set_to_none=True)
+    del out_rows, loss
+    full = model(x, g)
+    loss2 = torch.nn.functional.nll_loss(full[idx], labels[idx])
+    loss2.backward()
+    assert torch.equal(full.detach()[idx], sel)                      # (the same forward kernels)
+    del full
+    for k, p in model.named_parameters():
+        a, b = fused_grads[k].double(), p.grad.double()
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        err = float((a - b).abs().max())
+        assert err <= 5e-5 * float(b.abs().max()), f"{k}: {err:.3e} vs {float(b.abs().max()):.3e}"
