@@ -69,6 +69,13 @@ class GraphConvolution(Module):
                 _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
                 return GraphConvFunction.apply(input, self.weight, self.bias, as_graph(adj), False,
                                                0.0, 0, True)
+            if (isinstance(adj, ShardedGraph) and input.dim() == 2 and input.is_cuda and adj._hinted_product
+                    and not adj.is_constant_input(input)
+                    and log_softmax_fusable(self.out_features, input.dtype)):
+                # last layer of a sharded model: log_softmax in the store of the launch that
+                # completes the rank's rows (after the halo rows have arrived)
+                return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
+                                                 self.bias, False, 0.0, 0, True)
             return torch.nn.functional.log_softmax(self.forward(input, adj), dim=-1)
         if input.dim() == 3:
             out = self._forward_batched(input, adj, relu)

@@ -486,7 +486,7 @@ class ShardedGraph:
             self.timing.append((tag, ev[0], ev[1]))
 
     def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0,
-                row_nonzero=None, own_flags=None):
+                row_nonzero=None, own_flags=None, log_softmax=False):
         """Exchange + local product.  `row_nonzero` (callable idx -> bool, see
         HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel;
         with `own_flags` (bool [n_local], the same information for all own rows) the local product
@@ -499,6 +499,8 @@ class ShardedGraph:
         arrival — see split_block()."""
         ev = self._tic(local)
         kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
+        if log_softmax:          # (in the store of the launch that completes the rows)
+            kw["log_softmax"] = True
         tag = "bwd_local" if transpose else "fwd_local"
         which = "bwd" if transpose else "fwd"
         if self.exchange_mode == "halo":
@@ -545,27 +547,31 @@ class ShardedSpMMFunction(torch.autograd.Function):
     """out_r = Â_r · allgather(support);  grad_support_r = (Âᵀ)_r · allgather(grad_out)."""
 
     @staticmethod
-    def forward(ctx, sg, support_local, bias, relu=False, dropout_p=0.0, seed=0):
+    def forward(ctx, sg, support_local, bias, relu=False, dropout_p=0.0, seed=0, log_softmax=False):
         if dropout_p > 0.0 and not relu:
             raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
+        if log_softmax and relu:
+            raise RuntimeError("log_softmax cannot be combined with the fused ReLU / dropout")
         ctx.sg = sg
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
+        ctx.log_softmax = bool(log_softmax)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         out = sg.product(support_local, transpose=False, bias=bias, relu=relu,
-                         dropout_p=dropout_p, seed=seed)
-        if relu:
+                         dropout_p=dropout_p, seed=seed, log_softmax=log_softmax)
+        if relu or log_softmax:
             ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         grad_support = None
-        out = ctx.saved_tensors[0] if ctx.relu else None
+        out = ctx.saved_tensors[0] if (ctx.relu or ctx.log_softmax) else None
         # grad_bias is this rank's partial sum: summed over ranks by allreduce_grads
         sg = ctx.sg
         grad_out, grad_bias, hint = sg._bwd(grad_out, out, ctx.relu, ctx.scale,
-                                            ctx.has_bias and ctx.needs_input_grad[2])
+                                            ctx.has_bias and ctx.needs_input_grad[2],
+                                            **({"log_softmax": True} if ctx.log_softmax else {}))
         if ctx.needs_input_grad[1]:
             grad_out = grad_out.contiguous()
             row_nonzero = flags = None
@@ -578,7 +584,7 @@ class ShardedSpMMFunction(torch.autograd.Function):
                 row_nonzero = lambda idx: flags[idx]
             grad_support = sg.product(grad_out, transpose=True, row_nonzero=row_nonzero,
                                       own_flags=flags if row_nonzero is not None else None)
-        return None, grad_support, grad_bias, None, None, None
+        return None, grad_support, grad_bias, None, None, None, None
 
 
 class ShardedInputLayerFunction(torch.autograd.Function):
@@ -614,13 +620,18 @@ class ShardedInputLayerFunction(torch.autograd.Function):
             sg._toc(ev, "fwd")       # (the window of the product, as in the other branch)
             ev = None
             zb = None
+            ctx.z_bound = None
             if x_local.dtype == torch.float32:
                 xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
                     x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
-                zb = sg.A.inf_norm() * xb * 1.0001
-            out = layer_gemm(z, weight, zb, bias=bias, relu=relu, **kw)
+                zb = ctx.z_bound = sg.A.inf_norm() * xb * 1.0001
+            y_max = torch.zeros(1, dtype=torch.float32, device=z.device) if zb is not None else None
+            out = layer_gemm(z, weight, zb, y_max, bias=bias, relu=relu, **kw)
             if out is None:
                 z = None
+            elif y_max is not None:
+                from .spmm import remember_absmax
+                remember_absmax(out, y_max)          # the next layer's GEMM scales by it
         ctx.reassoc = out is not None
         if out is None:
             sup_own = _dense_forward(x_local, weight)
@@ -641,7 +652,12 @@ class ShardedInputLayerFunction(torch.autograd.Function):
                                             ctx.has_bias and ctx.needs_input_grad[4])
         grad_w = None
         if ctx.needs_input_grad[3] and ctx.reassoc:
-            grad_w = _weight_grad(x_local, grad_pre.contiguous())     # (x_local is z_r = Â_r·X here)
+            # (x_local is z_r = Â_r·X here.)  With both maxima known — ‖Â‖∞·max|X| and the maximum the
+            # GEMM above this layer reported for grad_out — the gather-fused MFMA kernel runs
+            from .spmm import known_absmax
+            g_bound = known_absmax(grad_out) if ctx.z_bound is not None else None
+            grad_w = _weight_grad(x_local, grad_pre.contiguous(), ctx.z_bound,
+                                  g_bound * ctx.scale if g_bound is not None else None)
         elif ctx.needs_input_grad[3]:
             grad_pre = grad_pre.contiguous()
             # rows of Â_r · X that meet an all-zero row of grad_pre add nothing: with the bitmap

@@ -670,7 +670,11 @@ def _dense_grads(input, weight, grad, need_in, need_w, rows=None):
             grad_in.index_copy_(0, rows, part)
         return grad_in, grad_w
     if need_in:
-        grad_in = gemm_xw256(grad, weight.t().contiguous())
+        y_max = torch.zeros(1, dtype=torch.float32, device=grad.device) \
+            if (grad.is_cuda and grad.dtype == torch.float32) else None
+        grad_in = gemm_xw256(grad, weight.t().contiguous(), None, y_max)
+        if grad_in is not None and y_max is not None and _gemm_scheme == "h2":
+            remember_absmax(grad_in, y_max)      # (the layer below bounds its masked gradient by it)
         if grad_in is None:
             grad_in = gemm_bf16(grad, weight.t().contiguous())
         if grad_in is None:
@@ -700,7 +704,8 @@ class DenseMMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, weight):
         ctx.save_for_backward(input, weight)
-        return _dense_forward(input, weight)
+        bound = known_absmax(input) if (input.is_cuda and input.dtype == torch.float32) else None
+        return _dense_forward(input, weight, bound)
 
     @staticmethod
     def backward(ctx, grad):
@@ -826,9 +831,12 @@ class GraphConvFunction(torch.autograd.Function):
                     grad_pre = torch.where(keep, grad_pre, torch.zeros_like(grad_pre[:1]))
             if grad_w is None:
                 grad_pre = grad_pre.contiguous()
-                grad_w = _weight_grad(z, grad_pre, ctx.z_bound,
-                                      torch.linalg.vector_norm(grad_pre, ord=float("inf")).reshape(1)
-                                      if ctx.z_bound is not None else None)
+                g_bound = None
+                if ctx.z_bound is not None:      # |mask(grad_out)| <= scale * max|grad_out|
+                    g_bound = known_absmax(grad_out)
+                    g_bound = g_bound * ctx.scale if g_bound is not None else \
+                        torch.linalg.vector_norm(grad_pre, ord=float("inf")).reshape(1)
+                grad_w = _weight_grad(z, grad_pre, ctx.z_bound, g_bound)
             return None, grad_w, grad_bias, None, None, None, None, None
         c_flags = rows = None
         compact = sync_ok and hint is not None
