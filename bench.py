@@ -321,9 +321,13 @@ def main():
         if reference_call:      # upstream's literal lines (train.py:140-157): no `rows=` hint
             out = fwd_model(x, adj)
             loss = F.nll_loss(out[idx_train].float(), labels_train)
-        elif world > 1:
+        elif world > 1 and dense_loss:
             out = fwd_model(x, adj)
-            loss = fwd_model.nll_loss(out.float(), labels, None if dense_loss else idx_train)
+            loss = fwd_model.nll_loss(out.float(), labels, None)
+        elif world > 1:
+            # every rank names the rows of its block the loss reads: one autograd node per rank,
+            # a static halo of gradient rows (pygcn_amd/sharded_fused.py)
+            loss = fwd_model.nll_loss(fwd_model(x, adj, rows=idx_train).float(), labels_train)
         elif dense_loss:
             loss = F.nll_loss(fwd_model(x, adj).float(), labels)
         else:
@@ -501,7 +505,7 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_note = measured_traffic(args.config, dt) if world == 1 else \
             (None, "single-GPU figure only")
-        syncs = 0 if (args.spmm_only or world == 1) else None
+        syncs = 0
         line = {
             "metric": "SpMM GEdge/s + fwd+bwd ms/epoch, 10M-node synthetic CSR, feat_dim=256",
             "value": round(gedges, 4), "unit": "GEdge/s", "n_gpus": world,
@@ -543,7 +547,7 @@ def main():
             "host_syncs_note": ("none inside the timed region: the rows every gradient can be "
                                 "non-zero on follow from the graph and idx_train, computed once "
                                 "before the timed region (pygcn_amd/fused.py)") if world == 1 else
-                               "one count exchange per row-sparse gradient exchange (sharded.py)",
+                               "none in the timed region on the one-node path (the gradient halo is static)",
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
@@ -556,7 +560,7 @@ def main():
                               "forward pass and needs no sparse product in backward (0 ms); `value` "
                               "and `roofline` are the unrestricted forward products; the "
                               "dense-gradient epoch is reported beside it") if world == 1 else
-                             "layer 2: exchange of the NON-ZERO gradient rows + local transpose product; layer 1: none (grad_W1 = (A_r x X)^T x grad_pre reuses the forward pass's A_r x X) (pygcn_amd/sharded.py)",
+                             "layer 2: a STATIC halo of the labelled vertices' gradient rows (who sends what is fixed once per (graph, idx_train): one grouped P2P round of known sizes, no count exchange) + the product on the rank's [R2_r, R] block of A^T; layer 1: none (grad_W1 = (A_r x X)^T x grad_pre reuses the forward pass's A_r x X) (pygcn_amd/sharded_fused.py)",
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),

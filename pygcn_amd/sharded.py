@@ -218,6 +218,9 @@ class HaloExchange:
             halo_off.append(acc)
             acc += recv_counts[r]
         self.halo_off = halo_off
+        # global id of every halo row, in buffer order (owners ascending)
+        self.halo_global = torch.cat([need[r].to(torch.int64) + bounds[r] for r in range(world) if r != rank]) \
+            if world > 1 else torch.empty(0, dtype=torch.int64, device=dev)
         c = col_global.to(torch.int64)
         owner = (torch.searchsorted(b, c, right=True) - 1).clamp_(0, world - 1)
         idx = torch.searchsorted(needed, c)
@@ -469,9 +472,19 @@ class ShardedGraph:
     def constant_halo(self, t):
         """Halo rows of the registered constant input; collective on first use per version."""
         if self._const_halo is None or self._const_halo[0] != t._version:
-            self._const_halo = (t._version, self.halo.exchange(t.detach()))
+            halo = self.halo.exchange(t.detach())
+            m = torch.linalg.vector_norm(t.detach().float(), ord=float("inf")).reshape(1)
+            if halo.shape[0]:
+                m = torch.maximum(m, torch.linalg.vector_norm(halo.float(), ord=float("inf")).reshape(1))
+            self._const_halo = (t._version, halo, m)
             self.n_const_exchanges += 1
         return self._const_halo[1]
+
+    def constant_absmax(self, t):
+        """max|[t ; halo rows of t]| (device float [1]) of the registered constant input, computed
+        with the halo exchange and kept with it."""
+        self.constant_halo(t)
+        return self._const_halo[2]
 
     def _tic(self, like):
         if self.timing is None or not like.is_cuda:
@@ -622,8 +635,9 @@ class ShardedInputLayerFunction(torch.autograd.Function):
             zb = None
             ctx.z_bound = None
             if x_local.dtype == torch.float32:
-                xb = torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
-                    x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local)
+                xb = sg.constant_absmax(x_local) if sg.is_constant_input(x_local) else (
+                    torch.maximum(absmax_cached(x_local), torch.linalg.vector_norm(
+                        x_halo, ord=float("inf")).reshape(1)) if x_halo.shape[0] else absmax_cached(x_local))
                 zb = ctx.z_bound = sg.A.inf_norm() * xb * 1.0001
             y_max = torch.zeros(1, dtype=torch.float32, device=z.device) if zb is not None else None
             out = layer_gemm(z, weight, zb, y_max, bias=bias, relu=relu, **kw)
@@ -684,12 +698,35 @@ class ShardedGCN(torch.nn.Module):
         super().__init__()
         self.model, self.sg = model, sg
         self._flat = None
+        self._row_sets = {}
 
-    def forward(self, x_local, sg=None):
+    def forward(self, x_local, sg=None, rows=None):
+        """`rows` (extension, like GCN.forward): local row ids the loss reads — returns
+        `output[rows]` and, where the shapes allow, runs the whole step of this rank as one autograd
+        node with a static halo of gradient rows (pygcn_amd/sharded_fused.py).  EVERY rank must
+        pass its rows on the same call (the first call per row set builds the structure
+        collectively)."""
         sg = sg if sg is not None else self.sg
         if sg.exchange_mode == "halo" and not x_local.requires_grad:
             sg.register_constant_input(x_local)    # the feature rows: exchanged once, then kept
-        return self.model(x_local, sg)
+        if rows is None:
+            return self.model(x_local, sg)
+        from . import sharded_fused as sf
+        from .spmm import dropout_seed_for
+        if not sf.fusable(sg, self.model, x_local):
+            return self.model(x_local, sg)[rows]
+        key = (rows.data_ptr(), rows.numel(), rows._version, rows.dtype)
+        hit = self._row_sets.get(key)
+        if hit is None:
+            if len(self._row_sets) >= 4:
+                self._row_sets.clear()
+            hit = self._row_sets[key] = (sf.ShardedRowSets(sg, rows), rows)      # (keeps `rows` alive)
+        m = self.model
+        p = m.dropout if m.training else 0.0
+        seed = dropout_seed_for(x_local) if p > 0.0 else 0
+        return sf.ShardedGCN2RowsFunction.apply(sg, hit[0], x_local, sg.constant_halo(x_local),
+                                                m.gc1.weight, m.gc1.bias, m.gc2.weight, m.gc2.bias,
+                                                float(p), seed)
 
     def nll_loss(self, logp_local, labels_local, idx_local=None):
         """This rank's share of the global-mean NLL over the (optionally index-selected) nodes of

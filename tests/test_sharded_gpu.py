@@ -101,6 +101,32 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
         extra = {"gc1.weight": budget[0].max().item(), "gc1.bias": budget[1].max().item()}
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             close(p.grad, q.grad, k + ".grad", rel=5e-5, extra=extra.get(k, 0.0))
+
+        # the one-node path per rank (rows= : static halo of gradient rows, transpose block) against
+        # the single-GPU one-node path on the union of the ranks' rows; unsorted rows on purpose
+        if exchange == "halo":
+            gen = torch.Generator().manual_seed(100 + rank)
+            idx_local = torch.randperm(sg.n_local, generator=gen)[: sg.n_local // 15].to(dev)
+            parts = [torch.empty(0, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather_object(parts, (idx_local.cpu() + sg.r0))
+            idx_global = torch.cat(parts).to(dev)
+            model.zero_grad(set_to_none=True)
+            xl = x[sg.r0:sg.r1].to(dev)
+            out_rows = smodel(xl, sg, rows=idx_local)
+            assert type(out_rows.grad_fn).__name__ == "ShardedGCN2RowsFunctionBackward"
+            lb = labels[sg.r0:sg.r1].to(dev)[idx_local]
+            loss_r = smodel.nll_loss(out_rows, lb)
+            loss_r.backward()
+            smodel.allreduce_grads()
+            ref.zero_grad(set_to_none=True)
+            rr = ref(x.to(dev), g, rows=idx_global)
+            rloss_r = torch.nn.functional.nll_loss(rr, labels.to(dev)[idx_global])
+            rloss_r.backward()
+            mine = slice(int(sum(p.numel() for p in parts[:rank])), int(sum(p.numel() for p in parts[:rank + 1])))
+            close(out_rows, rr[mine], "rows= log-probabilities")
+            assert abs(smodel.global_loss(loss_r) - rloss_r.item()) <= 1e-5 * abs(rloss_r.item())
+            for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+                close(p.grad, q.grad, "rows= " + k + ".grad", rel=5e-5)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -229,6 +255,18 @@ def _nccl_worker(rank, world, port, n, n_edges, out_dir):
             for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
                 e = (p.grad - q.grad).abs().max().item()
                 assert e <= 2e-5 * q.grad.abs().max().item(), (exchange, k, e)
+            if exchange == "halo":      # the one-node path: its collectives and its static P2P round on RCCL
+                model.zero_grad(set_to_none=True)
+                out_rows = smodel(x, sg, rows=idx)
+                assert type(out_rows.grad_fn).__name__ == "ShardedGCN2RowsFunctionBackward"
+                loss_r = smodel.nll_loss(out_rows, labels[idx])
+                loss_r.backward()
+                smodel.allreduce_grads()
+                assert abs(smodel.global_loss(loss_r) - rloss.item()) <= 1e-5 * abs(rloss.item())
+                assert (out_rows - rl[idx]).abs().max().item() <= 1e-5 * rl.abs().max().item()
+                for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+                    e = (p.grad - q.grad).abs().max().item()
+                    assert e <= 2e-5 * q.grad.abs().max().item(), ("rows=", k, e)
         # RCCL point-to-point through the path's own grouped-transfer helpers: at world size 1 the
         # only peer is the rank itself, which RCCL accepts — two messages to the same peer in one
         # group (the layout of the row-sparse gradient exchange), a zero-length one skipped on both

@@ -32,6 +32,12 @@ for exchange in ("halo", "allgather"):
         model.train(); opt.zero_grad(set_to_none=True)
         loss = sm.nll_loss(sm(x, sg).float(), labels, idx); loss.backward(); sm.allreduce_grads(); opt.step()
     res["sharded/" + exchange] = timed(step)
+    if exchange == "halo":
+        lt = labels[idx]
+        def step_rows():
+            model.train(); opt.zero_grad(set_to_none=True)
+            loss = sm.nll_loss(sm(x, sg, rows=idx).float(), lt); loss.backward(); sm.allreduce_grads(); opt.step()
+        res["sharded/halo, rows="] = timed(step_rows)
 rowptr, col, val = rmat_graph(n, e, seed=42, perm_seed=43, device=dev)
 g = CSRGraph(rowptr, col, val, (n, n))
 torch.manual_seed(1); model = GCN(F, F, F, dropout=0.5).to(dev)
