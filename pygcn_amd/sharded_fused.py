@@ -24,7 +24,6 @@ import torch
 import torch.distributed as dist
 
 from . import spmm as _spmm
-from .graph import CSRGraph
 from .sharded import HaloExchange
 from .spmm import _dense_forward, _weight_grad, gemm_xw256, log_softmax_fusable
 
@@ -91,9 +90,9 @@ class ShardedRowSets:
         rp = torch.zeros(self.n2 + 1, dtype=torch.int64, device=dev)
         if erow.numel():
             torch.cumsum(torch.bincount(dst, minlength=self.n2), 0, out=rp[1:])
-        self.at_block = CSRGraph(rp.to(torch.int32 if erow.numel() < 2 ** 31 - 1 else torch.int64),
-                                 col_c.to(torch.int32), eval_.contiguous(),
-                                 (self.n2, self.n_u + self.hx.n_halo))
+        self.at_block = sg._graph_factory(rp.to(torch.int32 if erow.numel() < 2 ** 31 - 1 else torch.int64),
+                                          col_c.to(torch.int32), eval_.contiguous(),
+                                          (self.n2, self.n_u + self.hx.n_halo))
 
 
 def fusable(sg, model, x_local):

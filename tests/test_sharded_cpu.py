@@ -303,3 +303,56 @@ def test_transpose_by_exchange_degenerate_bounds(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_transpose_worker, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(4)]
+
+
+def _rowsets_worker(rank, world, port, n, n_edges, out_dir):
+    """Structure of the sharded one-node path (pygcn_amd/sharded_fused.py) on CPU: the static halo
+    of gradient rows and the [R2_r, R] block of each rank's rows of the transpose must reproduce
+    rows R2_r of Aᵀ·G for a G that is non-zero on the union of the ranks' loss rows only."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import scipy.sparse as sp
+    import torch.distributed as dist
+    from pygcn_amd.sharded import ShardedGraph
+    from pygcn_amd.sharded_fused import ShardedRowSets
+    from pygcn_amd.utils import rmat_graph
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rowptr, col, val = rmat_graph(n, n_edges, seed=9, device="cpu")
+        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, graph_factory=_CpuGraph,
+                                          spmm_fn=_cpu_spmm, bwd_fn=_cpu_bwd)
+        gen = torch.Generator().manual_seed(50 + rank)
+        k = 0 if (world > 2 and rank == 1) else max(1, sg.n_local // 7)      # one rank without loss rows
+        rows_local = torch.randperm(sg.n_local, generator=gen)[:k]
+        rs = ShardedRowSets(sg, rows_local)
+        assert rs.n_u == k and rs.at_block.shape == (rs.n2, rs.n_u + rs.hx.n_halo)
+        # G: random on the union of the loss rows, zero elsewhere (every rank builds the same G)
+        parts = [None] * world
+        dist.all_gather_object(parts, (rows_local + sg.r0))
+        r_global = torch.sort(torch.cat(parts)).values
+        C = 5
+        G = torch.zeros(n, C, dtype=torch.float64)
+        G[r_global] = torch.from_numpy(np.random.default_rng(77).standard_normal((r_global.numel(), C)))
+        a = sp.csr_matrix((val.numpy().astype(np.float64), col.numpy(), rowptr.numpy()), shape=(n, n))
+        want = torch.from_numpy((a.T @ G.numpy())[sg.r0:sg.r1])              # my rows of Aᵀ·G
+        # what the backward pass does: my compact rows, the static exchange, the block product
+        gp = G[sg.r0:sg.r1][rs.rows_u].float()
+        halo, pending = rs.hx.exchange_begin(gp)
+        rs.hx.exchange_end(pending)
+        got = _cpu_spmm(rs.at_block, gp, B2=halo) if rs.n_u else (
+            _cpu_spmm(rs.at_block, halo) if halo.shape[0] else torch.zeros(rs.n2, C))
+        assert np.abs(got.numpy() - want[rs.rows2].numpy()).max() <= 1e-5 * max(1e-30, want.abs().max().item())
+        outside = torch.ones(sg.n_local, dtype=torch.bool)
+        outside[rs.rows2] = False
+        assert float(want[outside].abs().max()) == 0.0 if outside.any() else True
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_static_gradient_halo_and_transpose_block(tmp_path, world):
+    import torch.multiprocessing as mp
+    mp.spawn(_rowsets_worker, args=(world, _free_port(), 900, 6000, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
