@@ -194,6 +194,23 @@ def _bf16_worker(rank, world, port, n, n_edges, out_dir):
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             assert p.grad is not None and torch.isfinite(p.grad).all()
             close(p.grad, q.grad, k + ".grad", 2.0 ** -4)
+        # the one-node path per rank at bf16 (compact rows through index_select + hipBLASLt)
+        idx_local = torch.arange(sg.n_local // 10, device=dev)
+        parts = [None] * world
+        dist.all_gather_object(parts, (idx_local.cpu() + sg.r0))
+        idx_global = torch.cat(parts).to(dev)
+        model.zero_grad(set_to_none=True)
+        out_rows = smodel(x[sg.r0:sg.r1].to(dev), sg, rows=idx_local)
+        assert type(out_rows.grad_fn).__name__ == "ShardedGCN2RowsFunctionBackward"
+        smodel.nll_loss(out_rows.float(), labels[sg.r0:sg.r1].to(dev)[idx_local]).backward()
+        smodel.allreduce_grads()
+        ref.zero_grad(set_to_none=True)
+        rr = ref(x.to(dev), CSRGraph(rowptr, col, val, (n, n)), rows=idx_global)
+        torch.nn.functional.nll_loss(rr.float(), labels.to(dev)[idx_global]).backward()
+        lo = int(sum(p.numel() for p in parts[:rank]))
+        close(out_rows, rr[lo:lo + idx_local.numel()], "rows= logp", 2.0 ** -6)
+        for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            close(p.grad, q.grad, "rows= " + k + ".grad", 2.0 ** -4)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
