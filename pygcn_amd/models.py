@@ -39,7 +39,14 @@ class GCN(nn.Module):
         x = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
         # F.log_softmax(gc2(x, adj), dim=1) — in the SpMM's store when a row fits one wavefront
         # (dim=1 for the reference's [N, C]; the last dim if batched)
-        return self.gc2(x, adj, log_softmax=True)
+        out = self.gc2(x, adj, log_softmax=True)
+        if (self.training and out.requires_grad and out.dim() == 2 and out.is_cuda
+                and type(adj).__name__ != "ShardedGraph"):
+            # upstream's next line is `output[idx_train]`: let that selection hand the backward pass
+            # the rows instead of a dense gradient (pygcn_amd/rowgrad.py)
+            from pygcn_amd.rowgrad import RowSelectable
+            out = out.as_subclass(RowSelectable)
+        return out
 
     def _forward_rows(self, x, adj, rows, keep_full):
         import torch

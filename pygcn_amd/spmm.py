@@ -790,6 +790,7 @@ class GraphConvFunction(torch.autograd.Function):
                 ctx.save_for_backward(z, weight, *([out] if relu else []))
                 return out
             del z
+        ctx.x_bound = x_bound
         support = _dense_forward(input, weight, x_bound)
         out = spmm_csr(graph, support, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
                        log_softmax=log_softmax)
@@ -800,7 +801,91 @@ class GraphConvFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    def _backward_rows(ctx, grad):
+        """The backward pass for a row-sparse gradient (pygcn_amd/rowgrad.py): `grad.rows` are the only
+        rows of grad_out that can be non-zero.  Returns the gradient tuple, or None where this
+        route does not apply (the caller then continues with the dense tensor)."""
+        from . import fused
+        from .rowgrad import RowGrad
+        input, weight = ctx.saved_tensors[:2]
+        out = ctx.saved_tensors[2] if (ctx.relu or ctx.log_softmax) else None
+        need_in, need_w, need_b = ctx.needs_input_grad[:3]
+        graph, rows, vals = ctx.graph, grad.rows, grad.values
+        if not isinstance(graph, CSRGraph) or rows.numel() == 0 or vals.dtype != input.dtype:
+            return None
+        dev, dt = vals.device, vals.dtype
+        f32 = dt == torch.float32
+        if ctx.log_softmax:
+            # ---- last layer: log_softmax backward on the compact rows, then Âᵀ on its block
+            rs = fused.row_sets(graph, rows)
+            out_rows = out.index_select(0, rs.rows_user)
+            one_pass = backward_with_colsum(vals.contiguous(), out_rows, log_softmax=True) \
+                if not rs.has_duplicates else None
+            if one_pass is not None:
+                gp, colsum, _ = one_pass
+                grad_bias = colsum if need_b else None
+            else:
+                g32 = vals.float()
+                gp = (g32 - out_rows.float().exp() * g32.sum(1, keepdim=True)).to(dt)
+                grad_bias = gp.float().sum(0).to(dt) if need_b else None
+            if rs.has_duplicates:
+                gp = torch.zeros((rs.n_u, gp.shape[1]), dtype=dt, device=dev).index_add_(0, rs.inverse, gp)
+            elif not rs.sorted_unique:
+                gp = torch.empty_like(gp).index_copy_(0, rs.inverse, gp)
+            if not (need_in or need_w):
+                return None, None, grad_bias, None, None, None, None, None
+            grad_sup = spmm_csr(rs.at_block, gp.contiguous(), tag="bwd")          # [|R2|, Fout], compact
+            gs_bound = (graph.t().inf_norm() * torch.linalg.vector_norm(gp, ord=float("inf")) * 1.0001) \
+                if f32 else None
+            grad_w = grad_in = None
+            if need_w:
+                grad_w = weight_grad_rows(input, grad_sup, rs.rows2_padded, None, ctx.x_bound, gs_bound,
+                                          n_list=rs.n2) if (f32 and ctx.x_bound is not None
+                                                            and _gemm_scheme == "h2") else None
+                if grad_w is None:
+                    grad_w = _weight_grad(input.index_select(0, rs.rows2), grad_sup)
+            if need_in:
+                wt = weight.t().contiguous()
+                y_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
+                part = gemm_xw256(grad_sup, wt, gs_bound, y_max)
+                if part is None:
+                    part, y_max = gemm_bf16(grad_sup, wt), None
+                if part is None:
+                    part, y_max = torch.mm(grad_sup, wt), None
+                grad_in = RowGrad(rs.rows2, part, input.shape[0],
+                                  meta={"padded": rs.rows2_padded, "absmax": y_max})
+            return grad_in, grad_w, grad_bias, None, None, None, None, None
+        if ctx.reassoc and not need_in:
+            # ---- a first layer evaluated as (A·x)·W: mask on the compact rows, grad_W from the saved z
+            meta = grad.meta or {}
+            if meta.get("padded") is None:        # (rows of unknown structure: sorted-unique lists only)
+                return None
+            g = vals
+            bound = meta.get("absmax")
+            if ctx.relu:
+                g = relu_dropout_backward(vals.contiguous(), out.index_select(0, rows), ctx.scale)
+                bound = bound * ctx.scale if bound is not None else None
+            grad_bias = None
+            if need_b:
+                sums = backward_with_colsum(g) if g.is_contiguous() else None
+                grad_bias = sums[1] if sums is not None else g.float().sum(0).to(dt)
+            grad_w = None
+            if need_w:
+                grad_w = weight_grad_rows(input, g, meta["padded"], None, ctx.z_bound, bound,
+                                          n_list=rows.numel()) if (f32 and ctx.z_bound is not None) else None
+                if grad_w is None:
+                    grad_w = _weight_grad(input.index_select(0, rows), g)
+            return None, grad_w, grad_bias, None, None, None, None, None
+        return None
+
+    @staticmethod
     def backward(ctx, grad_out):
+        from .rowgrad import RowGrad
+        if isinstance(grad_out, RowGrad):
+            res = GraphConvFunction._backward_rows(ctx, grad_out)
+            if res is not None:
+                return res
+            grad_out = grad_out.dense()
         input, weight = ctx.saved_tensors[:2]
         out = ctx.saved_tensors[2] if (ctx.relu or ctx.log_softmax) else None
         need_in, need_w, need_b = ctx.needs_input_grad[:3]
