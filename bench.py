@@ -505,9 +505,11 @@ def main():
                 wall, _ = timed(3, ref_step)
                 extras["ms_per_step_reference_call"] = round(wall / 3 * 1e3, 3)
                 extras["reference_call_note"] = ("upstream's lines unchanged: output = model(features, adj); "
-                                                 "F.nll_loss(output[idx_train], labels[idx_train]) — "
-                                                 "without the rows= hint the layers find the zero gradient "
-                                                 "rows at run time (one bitmap pass + a host read per layer)")
+                                                 "F.nll_loss(output[idx_train], labels[idx_train]) — the "
+                                                 "selection output[idx_train] hands the layers' backward "
+                                                 "passes a row-sparse gradient (pygcn_amd/rowgrad.py), so "
+                                                 "they run on the same transpose block and compact rows "
+                                                 "as the rows= path, one autograd node per layer")
             except Exception as ex:
                 extras["ms_per_step_reference_call"] = None
                 extras["reference_call_note"] = f"failed: {ex!r}"

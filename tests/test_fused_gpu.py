@@ -206,3 +206,67 @@ def test_backward_pass_has_no_host_synchronisation(dev, monkeypatch):
     monkeypatch.undo()
     assert reads == [], reads
     assert torch.isfinite(l1).item()
+
+
+def test_upstream_lines_take_the_row_sparse_route(oracle, dev, poison):
+    """`output = model(x, adj); loss = nll_loss(output[idx], labels[idx])` — upstream's lines,
+    no `rows=`: the selection hands the layers a RowGrad (pygcn_amd/rowgrad.py) and the backward
+    pass runs on the transpose block and compact rows.  Same gradients as the oracle, as the
+    `rows=` path, and as the dense route (taken when the index is not a tensor)."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.rowgrad import RowGrad, RowSelectable
+    from pygcn_amd.utils import rmat_graph
+    import pygcn_amd.spmm as S
+    n = 30000
+    rowptr, col, val = rmat_graph(n, 300000, seed=23, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, 256), 8)).to(dev)
+    labels_np = np.random.default_rng(3).integers(0, 256, n)
+    labels = torch.from_numpy(labels_np).to(dev)
+    idx_np = np.random.default_rng(4).permutation(n)[: n // 12]               # unsorted
+    idx = torch.from_numpy(idx_np).to(dev)
+    torch.manual_seed(5)
+    model = GCN(256, 256, 256, dropout=0.0).to(dev)
+    model.train()
+    seen = []
+    orig = S.GraphConvFunction._backward_rows
+    S.GraphConvFunction._backward_rows = staticmethod(
+        lambda ctx, grad: (seen.append(type(grad).__name__), orig(ctx, grad))[1])
+    try:
+        out = model(x, g)
+        assert isinstance(out, RowSelectable) and not isinstance(out[idx], RowSelectable)
+        assert not isinstance(out + 1, RowSelectable) and torch.equal(out[idx], out.as_subclass(torch.Tensor)[idx])
+        loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
+        loss.backward()
+    finally:
+        S.GraphConvFunction._backward_rows = orig
+    assert seen == ["RowGrad", "RowGrad"]                                     # both layers took it
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref_loss, _, grads, _ = oracle.gcn2_loss_backward(x.cpu().numpy(), a, p, labels_np, idx_np)
+    assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss)
+    for k, v in grads.items():
+        assert_normwise(got[k].cpu(), v, 2e-5, "upstream lines: " + k + ".grad")
+    # the dense route (a list index is not intercepted) and the rows= route agree with it
+    for route in ("list", "rows"):
+        model.zero_grad(set_to_none=True)
+        if route == "list":
+            sel = model(x, g)[idx.tolist()]
+        else:
+            sel = model(x, g, rows=idx)
+        torch.nn.functional.nll_loss(sel, labels[idx]).backward()
+        for k, q in model.named_parameters():
+            assert_normwise(q.grad.cpu(), got[k].cpu().numpy(), 5e-5, route + " route: " + k)
+    # a second consumer of the output: the RowGrad meets a dense gradient and is materialised
+    model.zero_grad(set_to_none=True)
+    out = model(x, g)
+    (torch.nn.functional.nll_loss(out[idx], labels[idx]) + 1e-3 * out.mean()).backward()
+    both = {k: q.grad.clone() for k, q in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    out = model(x, g).as_subclass(torch.Tensor)
+    (torch.nn.functional.nll_loss(out[idx], labels[idx]) + 1e-3 * out.mean()).backward()
+    for k, q in model.named_parameters():
+        assert_normwise(both[k].cpu(), q.grad.cpu().numpy(), 5e-5, "two consumers: " + k)
+    rg = RowGrad(torch.tensor([2, 0, 2], device=dev), torch.ones(3, 4, device=dev), 5)
+    assert torch.equal(rg.dense(), torch.tensor([[1.] * 4, [0.] * 4, [2.] * 4, [0.] * 4, [0.] * 4], device=dev))
