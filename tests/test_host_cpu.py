@@ -283,3 +283,64 @@ def test_cache_file_format_round_trip_and_rejections(tmp_path):
     flipped[sec["a.val"]["offset"] + 401] ^= 0x40           # one bit inside a section's payload
     rejected(flipped, "CRC-32")
     cache.read_file(str(tmp_path / "bad.bin"), verify=False)   # (the same file opens unverified)
+
+
+def test_row_sparse_gradient_carrier_mechanics():
+    """pygcn_amd/rowgrad.py on CPU tensors (pure autograd plumbing, no kernels): a RowGrad travels
+    between custom autograd nodes, materialises for every other consumer, and `output[idx]` is
+    intercepted only for an int64 index tensor on a grad-requiring 2-D output."""
+    from pygcn_amd.rowgrad import RowGrad, RowSelectable
+
+    class Layer(torch.autograd.Function):
+        seen = []
+
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            Layer.seen.append(type(g).__name__)
+            if isinstance(g, RowGrad):
+                return RowGrad(g.rows, g.values @ w.t(), x.shape[0]), x.index_select(0, g.rows).t() @ g.values
+            return g @ w.t(), x.t() @ g
+
+    torch.manual_seed(0)
+    x = torch.randn(12, 4, requires_grad=True)
+    w1, w2 = torch.randn(4, 4, requires_grad=True), torch.randn(4, 3, requires_grad=True)
+    idx = torch.tensor([7, 1, 7, 3])                                  # unsorted, with a duplicate
+
+    def run(select):
+        for t in (x, w1, w2):
+            t.grad = None
+        out = Layer.apply(Layer.apply(x, w1), w2)
+        select(out).sum().backward()
+        return [t.grad.clone() for t in (x, w1, w2)]
+    Layer.seen.clear()
+    got = run(lambda o: o.as_subclass(RowSelectable)[idx])
+    assert Layer.seen == ["RowGrad", "RowGrad"]
+    Layer.seen.clear()
+    want = run(lambda o: o[idx])
+    assert Layer.seen == ["Tensor", "Tensor"]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, atol=1e-6)
+    assert not isinstance(got[0], RowGrad)                            # the leaf received a dense tensor
+    # a second consumer: the RowGrad is added to a dense gradient (materialised by dispatch)
+    Layer.seen.clear()
+    both = run(lambda o: o.as_subclass(RowSelectable)[idx].sum() + 0.5 * o.sum())
+    assert Layer.seen == ["Tensor", "Tensor"]
+    ref = run(lambda o: o[idx].sum() + 0.5 * o.sum())
+    for a, b in zip(both, ref):
+        assert torch.allclose(a, b, atol=1e-6)
+    # what is NOT intercepted: list / slice indices, no-grad outputs; results are plain tensors
+    out = Layer.apply(Layer.apply(x, w1), w2).as_subclass(RowSelectable)
+    assert type(out[idx.tolist()]) is torch.Tensor and out[idx.tolist()].grad_fn.name() != "SelectRowsFunctionBackward"
+    assert type(out[2:5]) is torch.Tensor and type(out + 1) is torch.Tensor and type(out.detach()) is torch.Tensor
+    assert out[idx].grad_fn.name() == "SelectRowsFunctionBackward"
+    with torch.no_grad():
+        assert out.detach().as_subclass(RowSelectable)[idx].grad_fn is None
+    rg = RowGrad(torch.tensor([2, 0, 2]), torch.ones(3, 2), 4)
+    assert tuple(rg.shape) == (4, 2) and torch.equal(rg.dense(), torch.tensor([[1., 1.], [0., 0.], [2., 2.], [0., 0.]]))
+    assert torch.equal(rg + 1, rg.dense() + 1)
