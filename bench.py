@@ -560,6 +560,7 @@ def main():
                            "start of every timed epoch (inside the timed region): every timed "
                            "epoch is epoch warmup+1") if snapshot is not None else None,
             "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
+            "ms_per_step_median_hip_events": round(float(np.median(per_step)), 3),
             "tolerance_note": "parity contract 1e-5 relative is per step (one forward/backward); "
                               "a 200-epoch Adam trajectory is gated at 1e-3 (chained fp32 steps)",
             "host_syncs_per_step": syncs,
