@@ -41,6 +41,7 @@ class GCN(nn.Module):
         # (dim=1 for the reference's [N, C]; the last dim if batched)
         out = self.gc2(x, adj, log_softmax=True)
         if (self.training and out.requires_grad and out.dim() == 2 and out.is_cuda
+                and out.shape[0] >= 16384             # (below that an epoch is launch-bound either way)
                 and type(adj).__name__ != "ShardedGraph"):
             # upstream's next line is `output[idx_train]`: let that selection hand the backward pass
             # the rows instead of a dense gradient (pygcn_amd/rowgrad.py)
