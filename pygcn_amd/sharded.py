@@ -29,15 +29,22 @@ same layer (reference pygcn/layers.py:32-38):
   * Constant input (the feature matrix X of the first layer, `ShardedGraph.register_constant_input`):
     its halo rows are exchanged ONCE and kept — each rank then holds the feature rows its block
     references, like it holds its block of Â — and the first layer needs no exchange at all:
-        forward   out_r = Â_r · ([X_r ; X_halo] · W)      (the halo rows' GEMM is recomputed locally
-                                                           every step instead of being received)
-        backward  grad_W partial = (Â_r · [X_r ; X_halo])ᵀ · grad_pre_r      (summed by the gradient
-                                                           all-reduce; X needs no gradient)
+        forward   z_r = Â_r · [X_r ; X_halo];  out_r = epilogue(z_r · W + b)     (one GEMM over the
+                                                           rank's own rows with the layer's epilogue in
+                                                           its store — 256 -> 256 fp32 / bf16 128-wide;
+                                                           other widths: Â_r · ([X_r ; X_halo] · W))
+        backward  grad_W partial = z_rᵀ · grad_pre_r       (the z_r of the forward pass; summed by the
+                                                           gradient all-reduce; X needs no gradient)
     so a 2-layer GCN epoch has 2 exchanges (layer 2 forward / backward) instead of 4.
+  * Pipelined by source block: a dense halo exchange posts its transfers, runs the product over
+    the entries that reference the rank's own rows while they fly, then the product over the halo
+    entries (`ShardedGraph.split_block`, `product`).
   * Backward exchanges are row-sparse (`HaloExchange.exchange_sparse`): the operand is the masked
     gradient, non-zero on the labelled vertices' rows only; only those rows travel (with their
     positions in the peer's request list), and their flags + the rank's own become the operand
-    hint of the local transpose product.
+    hint of the local transpose product.  With the loss rows named (`ShardedGCN(x, sg, rows=...)`)
+    the whole step of a rank is one autograd node and the gradient halo is static
+    (pygcn_amd/sharded_fused.py).
 
 The local product is `pygcn_amd.spmm.spmm_csr` (HIP) and the local backward pass
 `pygcn_amd.spmm._grad_pre_and_bias` (HIP).  `graph_factory` / `spmm_fn` / `bwd_fn` exist so the
