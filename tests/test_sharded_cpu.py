@@ -351,7 +351,7 @@ def _rowsets_worker(rank, world, port, n, n_edges, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_static_gradient_halo_and_transpose_block(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_rowsets_worker, args=(world, _free_port(), 900, 6000, str(tmp_path)), nprocs=world, join=True)
