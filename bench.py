@@ -2,7 +2,8 @@
 """bench.py — BASELINE.json's metric on MI355X: "SpMM GEdge/s + fwd+bwd ms/epoch, 10M-node
 synthetic CSR, feat_dim=256".
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or
+                                                            bare — it then starts its N ranks itself)
 
 A *step* is one full-graph training epoch of the upstream 2-layer GCN (256 -> 256 -> 256) on the
 synthetic R-MAT graph of config C4: 2 GEMM + 2 SpMM (over all rows) + bias + ReLU +
@@ -73,6 +74,10 @@ def parse():
     ap.add_argument("--reference-call", action="store_true",
                     help="profiling aid: the timed epoch uses upstream's unchanged lines "
                          "(model(features, adj); nll_loss(output[idx_train], ...)) instead of rows=")
+    ap.add_argument("--dense-loss", action="store_true",
+                    help="the timed epoch takes the NLL over ALL vertices (every gradient row is "
+                         "non-zero: the fork's live case, a reduction over all nodes — reference "
+                         "pygcn/train.py:151-155) instead of upstream's idx_train share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed side measurements (free-running and dense-loss epochs)")
@@ -85,6 +90,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: exchange, then one product (no source-block pipelining)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # launcher test
     ap.add_argument("--rehearsal", action="store_true",
                     help="N>1 code-path rehearsal on ONE GPU: all ranks share cuda:0, collectives "
                          "go over gloo staged through the host. Not a measurement.")
@@ -224,6 +230,39 @@ def measured_traffic(config, dt):
         return None, f"unreadable: {ex!r}"
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1 at a free port) BEFORE this
+    process has touched the GPU, let rank 0's JSON line through on the inherited stdout, and
+    return the launcher's exit status (non-zero as soon as one rank dies: torchrun then stops
+    the others).  Never exec-replaces the process."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    def on_term(signum, frame):      # the driver's timeout: leave through the except below
+        raise SystemExit(128 + signum)
+    signal.signal(signal.SIGTERM, on_term)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait()
+    except BaseException:            # Ctrl-C / SIGTERM on the parent: take the whole group down
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        raise
+
+
 def main():
     args = parse()
     if args.spmm_only and int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -231,14 +270,12 @@ def main():
     if args.cpu_baseline_child:
         cpu_baseline_child(args.cpu_baseline_child)
         return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))      # (no GPU call has happened in this process)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                             "(--nproc-per-node N)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if args.rehearsal:
         local_rank = 0
@@ -248,12 +285,14 @@ def main():
     import torch.distributed as dist
     if world > 1 and args.rehearsal:
         dist.init_process_group("gloo")
-        from pygcn_amd._rehearsal import install_host_staging
+        from tools.rehearsal import install_host_staging
         install_host_staging()
     elif world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.fail_rank == rank:       # (tests/test_bench_launch.py: a rank that dies after the rendezvous)
+        os._exit(3)
     from pygcn_amd import GCN, CSRGraph, _native
     from pygcn_amd import spmm as spmm_mod
     from pygcn_amd.functional import nll_loss      # (= F.nll_loss, mean reduction; gather / scatter)
@@ -271,6 +310,21 @@ def main():
     gen.manual_seed(44)
     kw = dict(item_cost=args.item_cost, long_thresh=args.long_thresh)
     peak_setup = None
+
+    def global_inputs(lo, hi):
+        """Rows [lo, hi) of the feature matrix and label vector of the WHOLE graph (seeds 44 / 45):
+        every world size trains on the same problem, so losses are comparable across N.  A rank
+        draws the full stream and keeps its slice (the generator has no skip-ahead by rows); the
+        temporary is released before the timed region."""
+        g = torch.Generator(device=dev)
+        g.manual_seed(44)
+        full = torch.randn(n, feat, generator=g, device=dev)
+        xs = full[lo:hi].to(tdtype).clone() if (lo, hi) != (0, n) else full.to(tdtype)
+        del full
+        lab = torch.randint(0, feat, (n,), device=dev,
+                            generator=torch.Generator(device=dev).manual_seed(45))[lo:hi].clone()
+        torch.cuda.empty_cache()
+        return xs, lab
     if world == 1:
         rowptr, col, val = rmat_graph(n, e, seed=42, perm_seed=43, device=dev)
         nnz = int(col.numel())
@@ -279,12 +333,12 @@ def main():
         graph = CSRGraph(rowptr, col, val, (n, n), **kw)
         graph.plan()
         graph.t().plan()
-        x = torch.randn(n, feat, generator=gen, device=dev).to(tdtype)
-        labels = torch.randint(0, feat, (n,), generator=torch.Generator(device=dev).manual_seed(45),
-                               device=dev)
+        x, labels = global_inputs(0, n)
+        torch.manual_seed(42)
         model = GCN(feat, feat, feat, dropout=args.dropout).to(dev).to(tdtype)
         adj = graph
         n_local, nnz_local = n, nnz
+        r0 = 0
         fwd_model = model
     else:
         # shard-local construction: a rank generates only its own rows of the SAME graph the
@@ -298,10 +352,9 @@ def main():
         t_gen = time.perf_counter() - t0
         peak_setup = torch.cuda.max_memory_allocated(dev)
         n_local, nnz_local = adj.n_local, adj.nnz_local
-        gen.manual_seed(44 + rank)
-        x = torch.randn(n_local, feat, generator=gen, device=dev).to(tdtype)
-        labels = torch.randint(0, feat, (n_local,), device=dev,
-                               generator=torch.Generator(device=dev).manual_seed(45 + rank))
+        r0 = adj.r0
+        # the rank's rows of the SAME feature matrix / labels the single-GPU run draws
+        x, labels = global_inputs(adj.r0, adj.r1)
         torch.manual_seed(42)
         model = GCN(feat, feat, feat, dropout=args.dropout).to(dev).to(tdtype)
         fwd_model = ShardedGCN(model, adj)
@@ -309,7 +362,9 @@ def main():
     # upstream epoch: loss on the labelled training nodes only (train.py:140-157 comments,
     # utils.py:370 idx_train = range(140) of 2708 -> the same 5.17 % head of the (seeded-permuted)
     # vertex list here)
-    n_train = max(1, int(n_local * 140 / 2708))
+    # (sharded: the global list cut by row block — a rank past the head holds no labelled vertex)
+    n_train_global = max(1, int(n * 140 / 2708))
+    n_train = max(0, min(n_train_global, r0 + n_local) - r0)
     idx_train = torch.arange(n_train, device=dev)
     torch.cuda.synchronize()
 
@@ -329,9 +384,12 @@ def main():
         elif world > 1:
             # every rank names the rows of its block the loss reads: one autograd node per rank,
             # a static halo of gradient rows (pygcn_amd/sharded_fused.py)
-            loss = fwd_model.nll_loss(fwd_model(x, adj, rows=idx_train).float(), labels_train)
+            loss = fwd_model.nll_loss(fwd_model(x, adj, rows=rows_handle).float(), labels_train)
         elif dense_loss:
-            loss = F.nll_loss(fwd_model(x, adj).float(), labels)
+            # a loss over ALL vertices (the fork's live loss reduces over every node, reference
+            # pygcn/train.py:151-155): pygcn_amd.functional.nll_loss = F.nll_loss (mean), whose
+            # gradient reaches the model's backward pass in structural form (one non-zero per row)
+            loss = nll_loss(fwd_model(x, adj).float(), labels)
         else:
             # upstream: F.nll_loss(output[idx_train], labels[idx_train]) (train.py:153) — the model is
             # told which rows the loss reads, so the backward pass runs on the rows that can be
@@ -368,7 +426,7 @@ def main():
             return
         if snapshot is not None:
             restore_snapshot()
-        epoch(reference_call=args.reference_call)
+        epoch(dense_loss=args.dense_loss, reference_call=args.reference_call)
 
     def timed(k, fn):
         """K calls of fn bracketed by barrier + synchronize; returns (wall seconds, per-call ms from
@@ -392,10 +450,13 @@ def main():
     # the transpose block (and, sharded, the static gradient halo) — built here, collectively,
     # whatever --warmup says
     sharded_rows_note = None
-    if not args.spmm_only and not args.reference_call:
+    rows_handle = idx_train
+    if not args.spmm_only and not args.reference_call and not args.dense_loss:
         try:
+            if world > 1:      # collective, once: the handle makes the per-epoch call lookup-free
+                rows_handle = fwd_model.prepare_rows(idx_train)
             with torch.no_grad():
-                fwd_model(x, adj, rows=idx_train)
+                fwd_model(x, adj, rows=rows_handle)
             torch.cuda.synchronize()
         except Exception as ex:
             # (N > 1 only: a deterministic failure of the one-node path's setup raises on every
@@ -403,6 +464,19 @@ def main():
             if world == 1:
                 raise
             sharded_rows_note = f"one-node path unavailable, layer-by-layer path timed instead: {ex!r}"
+    # the same number at every world size (same graph, features, labels, initial parameters; no
+    # dropout in eval mode): a sharded run that computes something else shows up here
+    loss_check = None
+    if not args.spmm_only:
+        model.eval()
+        with torch.no_grad():
+            out0 = fwd_model(x, adj)
+            if world > 1:
+                loss_check = fwd_model.global_loss(fwd_model.nll_loss(out0.float(), labels, idx_train))
+            else:
+                loss_check = float(F.nll_loss(out0[idx_train].float(), labels_train))
+        del out0
+        model.train()
     for _ in range(args.warmup):
         step()
     if not args.spmm_only and args.warmup > 0:
@@ -458,7 +532,40 @@ def main():
     recv_max = [int(v) for v in stats.tolist()[4:]]
 
     # ---------------------------------------------------------------- untimed side measurements
+    def count_host_syncs(fn):
+        """MEASURED: host synchronisations of one call of `fn` — torch's sync debug mode warns on
+        every synchronising call (`.item()`, `.tolist()`, `.cpu()`, `nonzero`, blocking copies)."""
+        import warnings
+        torch.cuda.synchronize()
+        try:
+            torch.cuda.set_sync_debug_mode("warn")
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                fn()
+            return sum("synchroniz" in str(w.message).lower() for w in caught)
+        except Exception as ex:                  # (the counter must never cost the bench line)
+            return f"unmeasured: {ex!r}"
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()
+
+    def dense_bwd_figures(l2_ms, l1_ms, n_steps):
+        """The transpose product at FULL height (dense gradient): ms, GEdge/s and its roofline
+        fraction (same algorithmic byte model as the forward product; Âᵀ has the same nnz)."""
+        if not l2_ms:
+            return {}
+        t2 = float(np.mean(l2_ms))
+        t1 = float(np.sum(l1_ms)) / max(1, n_steps) if l1_ms else 0.0
+        rp_b = 4 if nnz_local < 2 ** 31 - 1 else 8
+        alg_t = algorithmic_bytes(nnz_local, n_local, feat, esize, rp_b)
+        return {"spmm_bwd_dense_ms_layer2_layer1": [round(t2, 4), round(t1, 4)],
+                "spmm_bwd_dense_gedges": round(nnz_total / (t2 * 1e-3) / 1e9, 4),
+                "spmm_bwd_dense_roofline_frac": round(alg_t / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
     extras = {}
+    syncs = None
+    if not args.spmm_only:
+        syncs = count_host_syncs(step)
     if not args.spmm_only and not args.no_extras and snapshot is not None:
         snapshot_keep, snapshot = snapshot, None            # free-running: no restore
         _, free = timed(max(args.steps, 8), step)
@@ -481,16 +588,16 @@ def main():
                     epoch(dense_loss=True)
                 wall, _ = timed(3, dense_step)
                 spmm_mod.set_timing_records(None)
-                bd = [a.elapsed_time(b) for tag, a, b, _ in rec2 if tag == "bwd"]
+                bd2 = [a.elapsed_time(b) for tag, a, b, _ in rec2 if tag in ("bwd", "bwd_l2")]
+                bd1 = [a.elapsed_time(b) for tag, a, b, _ in rec2 if tag == "bwd_l1"]
                 extras["ms_per_step_dense_loss"] = round(wall / 3 * 1e3, 3)
-                if len(bd) == 3:     # layer 1 evaluated as (A x X) x W: no backward product of its own
-                    extras["spmm_bwd_dense_ms_layer2_layer1"] = [round(float(np.mean(bd)), 4), 0.0]
-                else:
-                    extras["spmm_bwd_dense_ms_layer2_layer1"] = [round(float(np.mean(bd[0::2])), 4),
-                                                                 round(float(np.mean(bd[1::2])), 4)]
-                extras["dense_loss_note"] = ("NLL over ALL rows instead of the idx_train share: "
-                                             "every gradient row is non-zero, no product can skip "
-                                             "operand rows")
+                extras.update(dense_bwd_figures(bd2, bd1, 3))
+                extras["host_syncs_per_step_dense_loss"] = count_host_syncs(dense_step)
+                extras["dense_loss_note"] = ("NLL over ALL rows instead of the idx_train share (the fork's "
+                                             "live loss reduces over every node, pygcn/train.py:151-155): "
+                                             "every gradient row is non-zero, no product can skip operand "
+                                             "rows; `python bench.py --dense-loss` times this epoch as the "
+                                             "main figure")
             except Exception as ex:                         # e.g. out of memory on a small device
                 spmm_mod.set_timing_records(None)
                 extras["ms_per_step_dense_loss"] = None
@@ -504,6 +611,7 @@ def main():
                     epoch(reference_call=True)
                 wall, _ = timed(3, ref_step)
                 extras["ms_per_step_reference_call"] = round(wall / 3 * 1e3, 3)
+                extras["host_syncs_per_step_reference_call"] = count_host_syncs(ref_step)
                 extras["reference_call_note"] = ("upstream's lines unchanged: output = model(features, adj); "
                                                  "F.nll_loss(output[idx_train], labels[idx_train]) — the "
                                                  "selection output[idx_train] hands the layers' backward "
@@ -524,7 +632,6 @@ def main():
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_note = measured_traffic(args.config, dt) if world == 1 else \
             (None, "single-GPU figure only")
-        syncs = 0
         line = {
             "metric": "SpMM GEdge/s + fwd+bwd ms/epoch, 10M-node synthetic CSR, feat_dim=256",
             "value": round(gedges, 4), "unit": "GEdge/s", "n_gpus": world,
@@ -536,8 +643,9 @@ def main():
             "config": {"workload": f"{args.config}: R-MAT(0.57,0.19,0.19,0.05) {n_total} nodes / "
                                    f"{e} sampled edges -> nnz {nnz_total} (dedupe + I, "
                                    f"row-normalized), feat_dim {feat}, 2-layer GCN "
-                                   f"{feat}->{feat}->{feat}, fwd+bwd+Adam, dropout {args.dropout}, NLL on the "
-                                   f"first 140/2708 of the vertices (upstream idx_train share)",
+                                   f"{feat}->{feat}->{feat}, fwd+bwd+Adam, dropout {args.dropout}, "
+                                   + ("NLL over ALL vertices (--dense-loss)" if args.dense_loss else
+                                      "NLL on the first 140/2708 of the vertices (upstream idx_train share)"),
                        "nodes": n_total, "nnz": nnz_total, "feat_dim": feat,
                        "parallelism": (f"row-block x{world} (the fixed {args.config} graph cut into "
                                        f"nnz-balanced row blocks, built shard-locally), "
@@ -555,7 +663,8 @@ def main():
                                           if args.exchange == "halo" else ""))
                        if world > 1 else "single GPU",
                        "mode": "spmm-only" if args.spmm_only else
-                               ("train-epoch (upstream's unchanged lines)" if args.reference_call else "train-epoch")},
+                               ("train-epoch (upstream's unchanged lines)" if args.reference_call else
+                                "train-epoch (loss over all vertices)" if args.dense_loss else "train-epoch")},
             "stationary": ("parameters + Adam state restored from the post-warm-up snapshot at the "
                            "start of every timed epoch (inside the timed region): every timed "
                            "epoch is epoch warmup+1") if snapshot is not None else None,
@@ -564,10 +673,9 @@ def main():
             "tolerance_note": "parity contract 1e-5 relative is per step (one forward/backward); "
                               "a 200-epoch Adam trajectory is gated at 1e-3 (chained fp32 steps)",
             "host_syncs_per_step": syncs,
-            "host_syncs_note": ("none inside the timed region: the rows every gradient can be "
-                                "non-zero on follow from the graph and idx_train, computed once "
-                                "before the timed region (pygcn_amd/fused.py)") if world == 1 else
-                               "none in the timed region on the one-node path (the gradient halo is static)",
+            "host_syncs_note": "MEASURED on one extra epoch of the timed kind after the timed region "
+                               "(torch.cuda.set_sync_debug_mode: every synchronising call warns); the "
+                               "dense-loss and upstream-lines epochs carry their own counts",
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,
             "spmm_bwd_ms_layer2_layer1": [round(bwd_l2, 4), round(bwd_l1, 4)],
@@ -584,6 +692,12 @@ def main():
             "spmm_launches_timed": len(fwd_ms) + len(bwd_ms),
             "spmm_local_fwd_ms_rank0": round(kernel_ms, 4),
             "graph_gen_s": round(t_gen, 2),
+            **(dense_bwd_figures(l2 or plain, l1, args.steps) if args.dense_loss and world == 1 else {}),
+            "loss_check": {"value": loss_check,
+                           "what": "eval-mode (no dropout) mean NLL on idx_train at the seeded initial "
+                                   "parameters, before the warm-up: the same graph, features, labels "
+                                   "and parameters at every --gpus N, so this number must agree across "
+                                   "world sizes to fp32 summation order"},
             **extras,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),

@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 21
+#define GCN_ABI_VERSION 22
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -72,6 +72,12 @@ typedef struct gcn_csr_plan {
     const int32_t *long_chunk0;/* [n_long+1] first chunk of every long row                   */
 } gcn_csr_plan;
 
+/* ABI history: 21 = round 2's surface.  22 (round 3): the dropout keep function draws eight 16-bit
+ * fields per Philox call instead of four 32-bit words and takes a row base (drop_row_base in both
+ * epilogue structs); + gcn_nll_log_softmax_backward_colsum.  The three options that leave
+ * rows of an output unwritten (c_skip_zero_rows, c_row_select, skip_zero_rows of the backward
+ * sweeps) are EXPERIMENTAL: the product uses them only inside single autograd nodes that own both
+ * the producer and every consumer of such a tensor (pygcn_amd/fused.py). */
 /* ABI version of the loaded library (GCN_ABI_VERSION). */
 int gcn_abi_version(void);
 
@@ -151,10 +157,14 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
  *   x = acc + bias[f]            (bias may be NULL)          — pygcn/layers.py:35-36
  *   x = max(x, 0)                if relu                     — F.relu,   pygcn/models.py:48 (upstream)
  *   x = keep ? x / (1 - p) : 0   if dropout_p > 0            — F.dropout, pygcn/models.py:50 (upstream)
- * The keep bit of element (row, f) is word (f & 3) of Philox4x32-10(counter = (row, f >> 2),
- * key = seed) compared with p * 2^32: a pure function of (seed, row, f), identical for every
- * kernel variant.  Because out > 0 <=> (pre-activation > 0 and kept), no mask is stored: the
- * backward pass is gcn_relu_dropout_backward on the output itself.
+ * The keep bit of element (row, f) is a pure function of (seed, drop_row_base + row, f), identical
+ * for every kernel variant (ABI 22: eight 16-bit fields per Philox4x32-10 call):
+ *     block = ((f >> 4) << 1) | ((f >> 2) & 1),   field = (((f >> 3) & 1) << 2) | (f & 3)
+ *     w     = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi))
+ *     keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= T,
+ *     T     = clamp(round(p * 65536), 1, 65535)      (p is honoured to 2^-17; p = 1/2 exactly)
+ * Because out > 0 <=> (pre-activation > 0 and kept), no mask is stored: the backward pass is
+ * gcn_relu_dropout_backward on the output itself.
  */
 typedef struct gcn_epilogue {
     const float *bias;   /* DEVICE fp32 [F] or NULL */
@@ -203,6 +213,9 @@ typedef struct gcn_epilogue {
      * stays 0, their memory is left untouched) — for a consumer that reads the flagged rows only.
      * Rows longer than the plan's long_thresh are always stored. */
     int32_t c_skip_zero_rows;
+    /* Added to the row index in the dropout counter (ABI 22): a row-block shard passes the global
+     * index of its first row, so the masks of a sharded run are those of the single-GPU run. */
+    int64_t drop_row_base;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */
@@ -250,6 +263,20 @@ int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void
                                      float *colsum, int64_t n_rows, int64_t F, float scale,
                                      uint32_t *row_bits, int32_t *nnz_rows, int skip_zero_rows,
                                      void *workspace, size_t workspace_bytes, void *stream);
+/*
+ * The same sweep for the gradient of a MEAN NLL LOSS OVER ALL ROWS — `F.nll_loss(output, labels)`,
+ * the reference's loss line (pygcn/train.py:153) without its index selection; the fork's live
+ * loss likewise reduces over every vertex (pygcn/train.py:151-155).  That gradient has one
+ * non-zero per row, grad_out[r][target[r]] = *coef (coef = -upstream / n_rows, DEVICE float), so it
+ * is never materialised: grad_pre = *coef * (onehot(target[r]) - exp(out[r])) and its column sums
+ * come straight from `out` (log-probabilities, [n_rows, F]) and the label vector `target` (DEVICE
+ * int64 [n_rows], entries in [0, F); an entry outside that range contributes no onehot term).
+ * 2 full-height streams (read out, write grad_pre) instead of 4.  Shape rules and scratch of
+ * gcn_log_softmax_backward_colsum.  (ABI 22.)
+ */
+int gcn_nll_log_softmax_backward_colsum(int dtype, const int64_t *target, const float *coef,
+                                        const void *out, void *grad_pre, float *colsum, int64_t n_rows,
+                                        int64_t F, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of
@@ -351,6 +378,8 @@ typedef struct gcn_gemm_epilogue {
     /* optional DEVICE int32 list [M]: output row r reads mask row mask_rows[r]; NULL = the input
      * row (x_rows[r], or r).  For a COMPACT input whose rows belong to listed rows of a full mask. */
     const int32_t *mask_rows;
+    /* added to the row index in the dropout counter (see struct gcn_epilogue; ABI 22) */
+    int64_t drop_row_base;
 } gcn_gemm_epilogue;
 
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);

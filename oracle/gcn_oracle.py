@@ -277,3 +277,37 @@ def train_trajectory(x, adj, params, labels, idx_train, epochs, lr=0.01, weight_
         losses.append(loss)
         opt.step(grads)
     return np.array(losses), np.array(accs), opt.p
+
+
+# ---------------------------------------------------------------- fused dropout (test checker)
+def dropout_keep(seed, rows, F, p, row_base=0):
+    """numpy restatement of the kernels' dropout keep function (include/gcn_spmm.h, struct
+    gcn_epilogue, ABI 22) — the stand-in for the mask `F.dropout` draws in the reference model
+    (pygcn/models.py:50 upstream).  bool [len(rows), F]; element (row, f):
+        block = ((f >> 4) << 1) | ((f >> 2) & 1),   field = (((f >> 3) & 1) << 2) | (f & 3)
+        w     = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi))
+        keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= clamp(round(p * 65536), 1, 65535)
+    with row = rows[i] + row_base."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    mask32 = np.uint64(0xFFFFFFFF)
+    rows = np.asarray(rows, np.int64) + np.int64(row_base)
+    f = np.arange(F, dtype=np.int64)
+    blk = ((f >> 4) << 1) | ((f >> 2) & 1)
+    fld = (((f >> 3) & 1) << 2) | (f & 3)
+    blocks = np.unique(blk)
+    r = np.repeat(rows.astype(np.uint64), len(blocks))
+    q = np.tile(blocks.astype(np.uint64), len(rows))
+    c = [r & mask32, r >> np.uint64(32), q, np.zeros_like(q)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(M0) * c[0], np.uint64(M1) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + np.uint64(W0)) & mask32, (k1 + np.uint64(W1)) & mask32
+    words = np.stack(c, axis=1).reshape(len(rows), len(blocks), 4)          # [row, block, word]
+    bpos = np.searchsorted(blocks, blk)
+    w = words[:, bpos, fld >> 1]                                              # [row, F]
+    bits = (w >> (np.uint64(16) * (fld & 1).astype(np.uint64))) & np.uint64(0xFFFF)
+    t = int(np.float64(np.float32(p)) * 65536.0 + 0.5)
+    thresh = min(65535, max(1, t))
+    return bits >= np.uint64(thresh)

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 21
+GCN_ABI_VERSION = 22
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -44,7 +44,7 @@ class GcnEpilogue(ctypes.Structure):
                 ("b2", ctypes.c_void_p), ("ldb2", ctypes.c_int64), ("b_split", ctypes.c_int64),
                 ("c_row_nonzero", ctypes.c_void_p), ("log_softmax", ctypes.c_int32),
                 ("seed_dev", ctypes.c_void_p), ("c_row_select", ctypes.c_void_p),
-                ("c_skip_zero_rows", ctypes.c_int32)]
+                ("c_skip_zero_rows", ctypes.c_int32), ("drop_row_base", ctypes.c_int64)]
 
 
 class GcnGemmEpilogue(ctypes.Structure):
@@ -52,7 +52,8 @@ class GcnGemmEpilogue(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("relu", ctypes.c_int32), ("dropout_p", ctypes.c_float),
                 ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p),
                 ("mask_src", ctypes.c_void_p), ("ld_mask", ctypes.c_int64),
-                ("mask_scale", ctypes.c_float), ("mask_rows", ctypes.c_void_p)]
+                ("mask_scale", ctypes.c_float), ("mask_rows", ctypes.c_void_p),
+                ("drop_row_base", ctypes.c_int64)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)
@@ -66,7 +67,8 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_plan_count_device", "gcn_plan_fill_device", "gcn_coo_to_csr_workspace_bytes",
            "gcn_coo_to_csr_device", "gcn_gemm_xw256_h2_workspace_bytes", "gcn_gemm_xw256_f32_h2",
            "gcn_gemm_bf16_workspace_bytes", "gcn_gemm_xw_bf16",
-           "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32")
+           "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32",
+           "gcn_nll_log_softmax_backward_colsum")
 
 _lib = None
 
@@ -144,6 +146,11 @@ def lib():
                                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_int,
                                                   ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_nll_log_softmax_backward_colsum.restype = ctypes.c_int
+    L.gcn_nll_log_softmax_backward_colsum.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_void_p]
     L.gcn_gemm_xw256_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_xw256_workspace_bytes.argtypes = []
     L.gcn_gemm_xw256_f32.restype = ctypes.c_int

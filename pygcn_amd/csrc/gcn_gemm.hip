@@ -42,6 +42,15 @@
 int gcn_internal_fail(int code, const char *msg);
 int gcn_internal_fail_hip(int hip_error, const char *where);
 
+// keep-threshold of the fused dropout: an element is kept iff its 16-bit field >= round(p * 2^16),
+// clamped to [1, 65535] for p > 0 (0 = dropout off) — include/gcn_spmm.h, struct gcn_epilogue
+static inline uint32_t gcn_dropout_threshold16(float p)
+{
+    if (!(p > 0.f)) return 0u;
+    const double t = (double)p * 65536.0 + 0.5;
+    return (uint32_t)std::min(65535.0, std::max(1.0, (double)(int64_t)t));
+}
+
 namespace {
 
 constexpr int kN = 256, kK = 256;
@@ -365,9 +374,10 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c)
 struct H2Epi {
     const float *bias;          // [256] or NULL
     int relu;
-    uint32_t drop_thresh;       // keep an element iff its 32 random bits >= drop_thresh (0: none)
+    uint32_t drop_thresh;       // keep an element iff its 16-bit field >= drop_thresh (0: none)
     float drop_scale;           // 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
+    int64_t drop_row_base;      // added to the row index in the dropout counter
     const uint64_t *seed_dev;   // optional: the seed as of execution time (hipGraph replays)
     const float *mask_src;      // optional backward mask: y = mask_src > 0 ? y * mask_scale : 0
     int64_t ld_mask;
@@ -375,8 +385,10 @@ struct H2Epi {
     float mask_scale;
 };
 
-// Philox4x32-10 — the SAME function of (seed, row, f >> 2) as the SpMM epilogue (gcn_spmm.hip):
-// element (row, f) is kept iff word f & 3 >= p * 2^32, whichever kernel stores the element
+// Philox4x32-10 — the SAME keep function of (seed, row, f) as the SpMM epilogue (gcn_spmm.hip,
+// include/gcn_spmm.h): block = ((f >> 4) << 1) | ((f >> 2) & 1), eight 16-bit fields per call.  A
+// lane of the transposed accumulator tile stores columns 32nb + 8g + 4h + (0..3) (h = lane half),
+// so groups g = 2q and 2q + 1 are fields 0..3 and 4..7 of ONE block: one call per 8 elements.
 __device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                           uint32_t k0, uint32_t k1, uint32_t (&out)[4])
 {
@@ -425,13 +437,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // scales (wave-uniform scalars)
     int x_exp = 14 - floor_log2f(*x_bound);
     x_exp = x_exp > 126 ? 126 : (x_exp < -126 ? -126 : x_exp);
+    bool poisoned = false;
     {
         const float b = *x_bound;
-        if (!(b > 0.f) || !(b <= 3.4028235e38f)) x_exp = 0;
+        if (!(b > 0.f)) x_exp = 0;                    // zero bound (an all-zero operand): no scaling
+        // A bound that is inf / NaN is the sentinel of an overflow upstream (y_absmax of a launch
+        // whose own bound was too small): it must not turn into silent zeros — poison the result.
+        poisoned = !(b <= 3.4028235e38f);
+        if (poisoned) x_exp = 0;
     }
     const float xs = pow2f(x_exp);
     const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
-    const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);   // exact steps
+    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
+    const float back_b = pow2f(back - back / 2);                      // exact steps
 
     u32x4 wreg[kH2WLoads];
     const unsigned char *wl = wimg;     // (re-made opaque per tile, see the tile loop)
@@ -488,7 +506,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     for (int c = 0; c < kH2Ring - 1; ++c) a_fetch(xrow, c, ar[c][0], ar[c][1]);
     w_store(0);
     split_frag(ar[0][0], ar[0][1], row_ok);
-    float vmax = 0.f;
+    uint32_t vmax = 0u;   // max of |y| as BITS: unsigned order = float order for finite values, and
+                          // inf / NaN patterns sort above every finite one (an overflow is never lost)
 
     for (; tile < n_tiles; tile += gridDim.x) {
 #ifndef GEMM_H2_EPI_PERSIST
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             const float *bias_p = ep.bias;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
+                uint32_t r4[4] = {0u, 0u, 0u, 0u};     // the 8 keep fields of a pair of column groups
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
@@ -591,23 +611,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     if (FWD_EPI && ep.drop_thresh != 0u) {                    // (uniform branch)
-                        uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
-                        if (ep.seed_dev != nullptr) {
-                            const uint64_t sd = *ep.seed_dev;
-                            k0 = (uint32_t)sd;
-                            k1 = (uint32_t)(sd >> 32);
+                        if ((g & 1) == 0) {          // fields 0..3 now, 4..7 at g + 1
+                            uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
+                            if (ep.seed_dev != nullptr) {
+                                const uint64_t sd = *ep.seed_dev;
+                                k0 = (uint32_t)sd;
+                                k1 = (uint32_t)(sd >> 32);
+                            }
+                            // (opaque: the first Philox round's product of this counter word with its
+                            //  constant does not depend on the tile, and hipcc hoists all of them
+                            //  out of the tile loop — spilled registers)
+                            uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)(lane >> 5);
+                            asm volatile("" : "+v"(cw));
+                            const int64_t drow = row + ep.drop_row_base;
+                            h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r4);
                         }
-                        uint32_t r4[4];
-                        // (opaque: the first Philox round's product of this counter word with its
-                        //  constant does not depend on the tile, and hipcc hoists all 16 of them
-                        //  out of the tile loop — 32 spilled registers)
-                        uint32_t cw = (uint32_t)(f >> 2);
-                        asm volatile("" : "+v"(cw));
-                        h2_philox((uint32_t)row, (uint32_t)(row >> 32), cw, 0u, k0, k1, r4);
-                        v.x = r4[0] >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
-                        v.y = r4[1] >= ep.drop_thresh ? v.y * ep.drop_scale : 0.f;
-                        v.z = r4[2] >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
-                        v.w = r4[3] >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
+                        const uint32_t w0 = (g & 1) ? r4[2] : r4[0], w1 = (g & 1) ? r4[3] : r4[1];
+                        v.x = (w0 & 0xFFFFu) >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
+                        v.y = (w0 >> 16) >= ep.drop_thresh ? v.y * ep.drop_scale : 0.f;
+                        v.z = (w1 & 0xFFFFu) >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
+                        v.w = (w1 >> 16) >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
                     }
                     if (mrow != nullptr) {
                         const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
@@ -620,7 +643,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     if (v.x == 1.2345e-30f)
 #endif
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    vmax = max(max(vmax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu)),
+                               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
                     // (keeps hipcc from running all 32 Philox chains of the tile side by side —
                     //  128 live registers on top of the accumulators)
                     if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
@@ -634,8 +658,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     }
     if (y_absmax != nullptr) {                 // |y| >= 0: float order == unsigned order of the bits
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
-        if (lane == 0 && vmax > 0.f) atomicMax(y_absmax, __float_as_uint(vmax));
+        for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+        if (lane == 0 && vmax != 0u) atomicMax(y_absmax, vmax);
     }
 }
 
@@ -710,7 +734,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
                     if (FWD_EPI) {
                         // the layer's forward epilogue on the fp32 accumulators (the layer evaluated
                         // as (Â·X)·W + b, its last stage being this GEMM): bias, ReLU, Philox
-                        // dropout — the keep function of gcn_spmm.hip, per (row, 4 columns)
+                        // dropout — the keep function of gcn_spmm.hip, one Philox call per 8 columns
+                        uint32_t r4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                         for (int gg = g; gg < g + 2; ++gg) {
                             const int f = 32 * nb + 8 * gg + 4 * h;                // first of 4 columns
@@ -728,18 +753,23 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
                                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             }
                             if (ep.drop_thresh != 0u) {                            // (uniform branch)
-                                uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
-                                if (ep.seed_dev != nullptr) {
-                                    const uint64_t sd = *ep.seed_dev;
-                                    k0 = (uint32_t)sd;
-                                    k1 = (uint32_t)(sd >> 32);
+                                if (gg == g) {       // one call for the pair of groups g, g + 1
+                                    uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
+                                    if (ep.seed_dev != nullptr) {
+                                        const uint64_t sd = *ep.seed_dev;
+                                        k0 = (uint32_t)sd;
+                                        k1 = (uint32_t)(sd >> 32);
+                                    }
+                                    uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)h;
+                                    asm volatile("" : "+v"(cw));       // (no hoisting of the first round)
+                                    const int64_t drow = row + ep.drop_row_base;
+                                    h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r4);
                                 }
-                                uint32_t r4[4];
-                                uint32_t cw = (uint32_t)(f >> 2);
-                                asm volatile("" : "+v"(cw));       // (no hoisting of the first round)
-                                h2_philox((uint32_t)row, (uint32_t)(row >> 32), cw, 0u, k0, k1, r4);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = r4[j] >= ep.drop_thresh ? v[j] * ep.drop_scale : 0.f;
+                                const uint32_t w0 = (gg & 1) ? r4[2] : r4[0], w1 = (gg & 1) ? r4[3] : r4[1];
+                                v[0] = (w0 & 0xFFFFu) >= ep.drop_thresh ? v[0] * ep.drop_scale : 0.f;
+                                v[1] = (w0 >> 16) >= ep.drop_thresh ? v[1] * ep.drop_scale : 0.f;
+                                v[2] = (w1 & 0xFFFFu) >= ep.drop_thresh ? v[2] * ep.drop_scale : 0.f;
+                                v[3] = (w1 >> 16) >= ep.drop_thresh ? v[3] * ep.drop_scale : 0.f;
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[nb][4 * gg + j] = v[j];
@@ -824,7 +854,10 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
     const float my_scale = pow2f(loads_g ? g_exp : a_exp);
     const int back = -(a_exp + g_exp);
-    const float back_a = pow2f(back / 2), back_b = pow2f(back - back / 2);
+    // (an inf / NaN bound = an overflow upstream: poison the result instead of scaling by 1)
+    const bool poisoned = !(*a_bound <= 3.4028235e38f) || !(*g_bound <= 3.4028235e38f);
+    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
+    const float back_b = pow2f(back - back / 2);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -991,10 +1024,9 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: forward epilogue and backward mask exclude each other");
         ep.bias = epi->bias;
         ep.relu = epi->relu ? 1 : 0;
-        ep.drop_thresh = epi->dropout_p > 0.f
-                             ? (uint32_t)std::min(4294967295.0, (double)epi->dropout_p * 4294967296.0) : 0u;
-        if (epi->dropout_p > 0.f && ep.drop_thresh == 0u) ep.drop_thresh = 1u;
+        ep.drop_thresh = gcn_dropout_threshold16(epi->dropout_p);
         ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.drop_row_base = epi->drop_row_base;
         ep.seed_lo = (uint32_t)epi->seed;
         ep.seed_hi = (uint32_t)(epi->seed >> 32);
         ep.seed_dev = epi->seed_dev;
@@ -1057,10 +1089,9 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
             return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: bias must be 16-byte aligned");
         ep.bias = epi->bias;
         ep.relu = epi->relu ? 1 : 0;
-        ep.drop_thresh = epi->dropout_p > 0.f
-                             ? (uint32_t)std::min(4294967295.0, (double)epi->dropout_p * 4294967296.0) : 0u;
-        if (epi->dropout_p > 0.f && ep.drop_thresh == 0u) ep.drop_thresh = 1u;
+        ep.drop_thresh = gcn_dropout_threshold16(epi->dropout_p);
         ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.drop_row_base = epi->drop_row_base;
         ep.seed_lo = (uint32_t)epi->seed;
         ep.seed_hi = (uint32_t)(epi->seed >> 32);
         ep.seed_dev = epi->seed_dev;

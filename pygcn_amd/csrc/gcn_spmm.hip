@@ -31,6 +31,15 @@
 
 #include "gcn_spmm.h"
 
+// keep-threshold of the fused dropout: an element is kept iff its 16-bit field >= round(p * 2^16),
+// clamped to [1, 65535] for p > 0 (0 = dropout off) — include/gcn_spmm.h, struct gcn_epilogue
+static inline uint32_t gcn_dropout_threshold16(float p)
+{
+    if (!(p > 0.f)) return 0u;
+    const double t = (double)p * 65536.0 + 0.5;
+    return (uint32_t)std::min(65535.0, std::max(1.0, (double)(int64_t)t));
+}
+
 namespace {
 
 constexpr int kWave = 64;
@@ -76,9 +85,10 @@ struct KParams {
     int32_t n_long;
     int32_t long_thresh;
     int32_t relu;
-    uint32_t drop_thresh;   // keep an element iff its 32 random bits >= drop_thresh (0: no dropout)
+    uint32_t drop_thresh;   // keep an element iff its 16 random bits >= drop_thresh (0: no dropout)
     float drop_scale;       // 1 / (1 - p)
     uint32_t seed_lo, seed_hi;
+    int64_t drop_row_base;  // added to the row index in the dropout counter (a shard's first row)
     const void *B2;          // optional second block of B: rows >= b_split live here (ldb2)
     int64_t ldb2;
     int32_t b_split;         // INT32_MAX when B is one block
@@ -182,8 +192,15 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so the dropout mask of element (row, f)
 // depends only on (seed, row, f) — never on which kernel variant, vector width, wave or launch
-// produced the row.  Element (row, f) uses word f & 3 of philox(counter = (row_lo, row_hi, f >> 2,
-// 0), key = seed).
+// produced the row.  One call yields 128 bits = EIGHT 16-bit keep fields (ABI 22; before: four
+// 32-bit words — half the integer multiplies per element now).  Element (row, f):
+//     block = ((f >> 4) << 1) | ((f >> 2) & 1)          counter word 2
+//     field = (((f >> 3) & 1) << 2) | (f & 3)           0..7: word field >> 1, half field & 1
+//     w     = philox(counter = (row_lo, row_hi, block, 0), key = seed)   (row incl. drop_row_base)
+//     keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= round(p * 65536)
+// The block groups columns {16c + 4b + (0..3), 16c + 4b + 8 + (0..3)} (b = bit 2 of f): exactly the
+// eight columns one lane of the MFMA GEMMs' transposed accumulator tile stores per 16-column
+// group (gcn_gemm.hip), so the GEMM epilogues need ONE call per eight stored elements too.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4])
 {
@@ -211,17 +228,26 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
         k0 = (uint32_t)sd;
         k1 = (uint32_t)(sd >> 32);
     }
+    row += p.drop_row_base;
     if (VEC == 1) {
-        philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)(f >> 2), 0u, k0, k1, r);
-        o[0] = (r[f & 3] >= p.drop_thresh) ? o[0] * p.drop_scale : 0.f;
+        const uint32_t blk = ((uint32_t)(f >> 4) << 1) | ((uint32_t)(f >> 2) & 1u);
+        const int fld = (((f >> 3) & 1) << 2) | (f & 3);
+        philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), blk, 0u, k0, k1, r);
+        const uint32_t w = (fld & 4) ? ((fld & 2) ? r[3] : r[2]) : ((fld & 2) ? r[1] : r[0]);
+        const uint32_t bits = (fld & 1) ? (w >> 16) : (w & 0xFFFFu);
+        o[0] = (bits >= p.drop_thresh) ? o[0] * p.drop_scale : 0.f;
     } else {
 #pragma unroll
-        for (int q = 0; q < VEC / 4; ++q) {
-            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)((f >> 2) + q), 0u, k0,
-                          k1, r);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                o[4 * q + i] = (r[i] >= p.drop_thresh) ? o[4 * q + i] * p.drop_scale : 0.f;
+        for (int q = 0; q < VEC / 4; ++q) {       // 4 consecutive columns = fields 4s .. 4s+3 of one block
+            const int fq = f + 4 * q;
+            const uint32_t blk = ((uint32_t)(fq >> 4) << 1) | ((uint32_t)(fq >> 2) & 1u);
+            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), blk, 0u, k0, k1, r);
+            const bool hi = ((fq >> 3) & 1) != 0;
+            const uint32_t w0 = hi ? r[2] : r[0], w1 = hi ? r[3] : r[1];
+            o[4 * q + 0] = ((w0 & 0xFFFFu) >= p.drop_thresh) ? o[4 * q + 0] * p.drop_scale : 0.f;
+            o[4 * q + 1] = ((w0 >> 16) >= p.drop_thresh) ? o[4 * q + 1] * p.drop_scale : 0.f;
+            o[4 * q + 2] = ((w1 & 0xFFFFu) >= p.drop_thresh) ? o[4 * q + 2] * p.drop_scale : 0.f;
+            o[4 * q + 3] = ((w1 >> 16) >= p.drop_thresh) ? o[4 * q + 3] * p.drop_scale : 0.f;
         }
     }
 }
@@ -832,6 +858,10 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const T *__restri
 // MODE 2 the backward of a fused log_softmax: grad_pre = g - exp(out) * rowsum(g), the row sum by
 // xor-shuffles over the row's CG <= 64 lanes; rows of g that are entirely zero (every vertex
 // outside idx_train) are written as zeros without reading `out`.
+// MODE 3 is MODE 2 for the gradient of a mean NLL loss over ALL rows (F.nll_loss(output, labels),
+// reference pygcn/train.py:153 without the index selection): g has one non-zero per row,
+// g[r][target[r]] = coef, so it is never materialised — grad_pre = coef * (onehot(target[r]) -
+// exp(out)), straight from `out` and the label vector: 2 instead of 4 full-height streams.
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ grad_out,
@@ -840,10 +870,13 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
                                                          float *__restrict__ partial, int64_t n_rows,
                                                          int F, float scale, int rows_per_block,
                                                          uint8_t *__restrict__ rowflag,
-                                                         int32_t *__restrict__ nnz_rows, int skip)
+                                                         int32_t *__restrict__ nnz_rows, int skip,
+                                                         const int64_t *__restrict__ target,
+                                                         const float *__restrict__ coef)
 {
     typedef typename Elem<T, VEC>::Raw Raw;
     __shared__ float red[256 * VEC];
+    const float cf = MODE == 3 ? *coef : 0.f;
     const int CG = F / VEC, RL = 256 / CG;         // column groups (16 B each), row lanes
     const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -859,8 +892,17 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
     for (int64_t r = r0 + rl; r < r1; r += RL) {
         const int64_t off = r * F + VEC * cg;
         float g[VEC];
-        Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
+        if (MODE != 3) Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
         Raw packed = {};
+        if (MODE == 3) {
+            const int64_t t = target[r] - VEC * cg;   // (one address per row: a broadcast load)
+            float o[VEC];
+            Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) g[i] = cf * ((t == i ? 1.f : 0.f) - expf(o[i]));
+            packed = Elem<T, VEC>::pack(g);
+            Elem<T, VEC>::unpack(packed, g);
+        }
         if (MODE == 1) {
             // lanes whose 16 bytes of grad_out are all zero produce zeros whatever `out` holds:
             // they skip its load (row-sparse gradients: most of the `out` traffic disappears)
@@ -1270,11 +1312,10 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.n_long = (int32_t)plan->n_long;
     kp.long_thresh = plan->long_thresh > 0 ? plan->long_thresh : kDefaultLongThresh;
     kp.relu = relu ? 1 : 0;
-    // keep iff rand32 >= p * 2^32  (p = 0 -> threshold 0 -> dropout off)
-    kp.drop_thresh = drop_p > 0.f ? (uint32_t)std::min(4294967295.0, (double)drop_p * 4294967296.0)
-                                  : 0u;
-    if (drop_p > 0.f && kp.drop_thresh == 0u) kp.drop_thresh = 1u;
+    // keep iff rand16 >= round(p * 2^16)  (p = 0 -> threshold 0 -> dropout off)
+    kp.drop_thresh = gcn_dropout_threshold16(drop_p);
     kp.drop_scale = 1.f / (1.f - drop_p);
+    kp.drop_row_base = ep ? ep->drop_row_base : 0;
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
     kp.seed_dev = ep ? ep->seed_dev : nullptr;
@@ -1383,7 +1424,8 @@ size_t gcn_bwd_colsum_workspace_bytes(int64_t n_rows, int64_t F, int dtype)
 static int bwd_colsum_impl(const char *who, int mode, int dtype, const void *grad_out, const void *out,
                            void *grad_pre, float *colsum, int64_t n_rows, int64_t F, float scale,
                            uint32_t *row_bits, int32_t *nnz_rows, int skip_zero_rows,
-                           void *workspace, size_t workspace_bytes, void *stream)
+                           void *workspace, size_t workspace_bytes, void *stream,
+                           const int64_t *target = nullptr, const float *coef = nullptr)
 {
     char msg[160];
     auto bad = [&](int code, const char *what) {
@@ -1396,13 +1438,14 @@ static int bwd_colsum_impl(const char *who, int mode, int dtype, const void *gra
     const int64_t vec = dtype == GCN_DTYPE_BF16 ? 8 : 4;
     if (n_rows < 0 || !colsum_shape_ok(F, dtype))
         return bad(GCN_E_BADARG, "F must be a multiple of the 16-byte lane width with F/width dividing 256");
-    if (mode == 2 && F / vec > 64)
+    if (mode >= 2 && F / vec > 64)
         return bad(GCN_E_BADARG, "a row must fit one wavefront (F / lane width <= 64)");
     if (row_bits != nullptr && F / vec > 64)   // a row spans several wavefronts: no per-row ballot
         return bad(GCN_E_BADARG, "row_bits / nnz_rows need F / lane width <= 64 (pass NULL for wider rows)");
     if (skip_zero_rows && (row_bits == nullptr || mode == 0))
         return bad(GCN_E_BADARG, "skip_zero_rows needs the row bitmap outputs and a result tensor");
-    if (colsum == nullptr || grad_out == nullptr || (out != nullptr && grad_pre == nullptr))
+    if (colsum == nullptr || (grad_out == nullptr && mode != 3) || (out != nullptr && grad_pre == nullptr)
+        || (mode == 3 && (target == nullptr || coef == nullptr || out == nullptr)))
         return bad(GCN_E_BADARG, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (nnz_rows != nullptr) {
@@ -1426,13 +1469,15 @@ static int bwd_colsum_impl(const char *who, int mode, int dtype, const void *gra
 #define GCN_LAUNCH_COLSUM(T, V, M)                                                                   \
     hipLaunchKernelGGL((bwd_colsum_kernel<T, V, M>), grid, block, 0, s, (const T *)grad_out,         \
                        (const T *)out, (T *)grad_pre, part, n_rows, (int)F, scale, rows_per_block,   \
-                       row_nonzero, nnz_rows, skip_zero_rows ? 1 : 0)
+                       row_nonzero, nnz_rows, skip_zero_rows ? 1 : 0, target, coef)
     if (dtype == GCN_DTYPE_F32) {
-        if (mode == 2) GCN_LAUNCH_COLSUM(float, 4, 2);
+        if (mode == 3) GCN_LAUNCH_COLSUM(float, 4, 3);
+        else if (mode == 2) GCN_LAUNCH_COLSUM(float, 4, 2);
         else if (mode == 1) GCN_LAUNCH_COLSUM(float, 4, 1);
         else GCN_LAUNCH_COLSUM(float, 4, 0);
     } else {
-        if (mode == 2) GCN_LAUNCH_COLSUM(bf16_t, 8, 2);
+        if (mode == 3) GCN_LAUNCH_COLSUM(bf16_t, 8, 3);
+        else if (mode == 2) GCN_LAUNCH_COLSUM(bf16_t, 8, 2);
         else if (mode == 1) GCN_LAUNCH_COLSUM(bf16_t, 8, 1);
         else GCN_LAUNCH_COLSUM(bf16_t, 8, 0);
     }
@@ -1467,6 +1512,15 @@ int gcn_log_softmax_backward_colsum(int dtype, const void *grad_out, const void 
     return bwd_colsum_impl("gcn_log_softmax_backward_colsum", 2, dtype, grad_out, out, grad_pre, colsum,
                            n_rows, F, 1.f, row_bits, nnz_rows, skip_zero_rows, workspace,
                            workspace_bytes, stream);
+}
+
+int gcn_nll_log_softmax_backward_colsum(int dtype, const int64_t *target, const float *coef,
+                                        const void *out, void *grad_pre, float *colsum, int64_t n_rows,
+                                        int64_t F, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return bwd_colsum_impl("gcn_nll_log_softmax_backward_colsum", 3, dtype, nullptr, out, grad_pre,
+                           colsum, n_rows, F, 1.f, nullptr, nullptr, 0, workspace, workspace_bytes,
+                           stream, target, coef);
 }
 
 int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,

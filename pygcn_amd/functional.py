@@ -6,6 +6,36 @@ torch's `nll_loss` kernels walk one row per thread: on the [|idx_train|, 256] sl
 scatter of one element per row into a zero tensor take 0.3 ms.  Same value, same gradient.
 """
 import torch
+import torch.utils._pytree as pytree
+
+
+class NLLGrad(torch.Tensor):
+    """The gradient of a mean NLL loss with respect to its [n, C] input: ONE non-zero per row,
+    `coef` (device float32 [1]) at column target[r].  A wrapper tensor without storage, like
+    rowgrad.RowGrad: the model's one-node backward pass (pygcn_amd/fused.py) recognises it and
+    forms coef·(onehot − exp(logp)) in one sweep without the [n, C] gradient ever existing
+    (10 GB at config C4); every other consumer sees the dense tensor (any operator on it
+    materialises it first)."""
+
+    @staticmethod
+    def __new__(cls, target, coef, shape, dtype):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=target.device,
+                                                requires_grad=False)
+        t.target, t.coef = target, coef
+        return t
+
+    def dense(self):
+        n = self.shape[0]
+        out = torch.zeros(tuple(self.shape), dtype=self.dtype, device=self.device)
+        return out.scatter_(1, self.target.view(-1, 1), self.coef.to(self.dtype).expand(n, 1))
+
+    def __repr__(self):
+        return f"NLLGrad(shape={tuple(self.shape)}, dtype={self.dtype})"
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a.dense() if isinstance(a, NLLGrad) else a     # noqa: E731
+        return func(*pytree.tree_map(conv, args), **pytree.tree_map(conv, kwargs or {}))
 
 
 class _NLLMean(torch.autograd.Function):
@@ -22,6 +52,8 @@ class _NLLMean(torch.autograd.Function):
     def backward(ctx, grad):
         (target,) = ctx.saved_tensors
         n = ctx.shape[0]
+        if grad.is_cuda and n > 0:       # structural form: nothing of size [n, C] is written here
+            return NLLGrad(target, (-grad / n).float().reshape(1), ctx.shape, ctx.dtype), None
         g = torch.zeros(ctx.shape, dtype=ctx.dtype, device=grad.device)
         g.scatter_(1, target.view(-1, 1), (-grad / n).to(ctx.dtype).expand(n, 1))
         return g, None

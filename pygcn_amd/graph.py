@@ -253,28 +253,7 @@ class CSRGraph:
         """The same schedule from the HOST planner (`gcn_plan_{count,fill}_host`), as numpy arrays
         — kept for callers that hold the row pointer on the host, and as the cross-check of the
         device planner (tests/test_ingest_gpu.py: array-for-array equality)."""
-        L = _native.lib()
-        rp_host = self.rowptr.cpu().numpy()
-        is64 = int(self.rowptr.dtype == torch.int64)
-        n_rows = self.shape[0]
-        ni, nc, nl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-        _native.check(L.gcn_plan_count_host(rp_host.ctypes.data, is64, n_rows, self.item_cost,
-                                            self.long_thresh, ctypes.byref(ni), ctypes.byref(nc),
-                                            ctypes.byref(nl)), "gcn_plan_count_host")
-        ni, nc, nl = ni.value, nc.value, nl.value
-        items = np.empty(max(2 * ni, 1), np.int32)
-        chunk_row = np.empty(max(nc, 1), np.int32)
-        chunk_e0 = np.empty(max(nc, 1), np.int64)
-        long_row = np.empty(max(nl, 1), np.int32)
-        long_chunk0 = np.empty(nl + 1, np.int32)
-        _native.check(L.gcn_plan_fill_host(rp_host.ctypes.data, is64, n_rows, self.item_cost,
-                                           self.long_thresh, items.ctypes.data, ni,
-                                           chunk_row.ctypes.data, chunk_e0.ctypes.data, nc,
-                                           long_row.ctypes.data, long_chunk0.ctypes.data, nl),
-                      "gcn_plan_fill_host")
-        return {"items": items[:2 * ni], "chunk_row": chunk_row[:nc], "chunk_e0": chunk_e0[:nc],
-                "long_row": long_row[:nl], "long_chunk0": long_chunk0,
-                "n_items": ni, "n_chunks": nc, "n_long": nl}
+        return host_schedule(self.rowptr.cpu().numpy(), self.shape[0], self.item_cost, self.long_thresh)
 
     def schedule_stats(self):
         p = self.plan()
@@ -369,6 +348,12 @@ class CSRGraph:
         from . import cache
         meta, arr = cache.read_file(path, verify=verify)
         dev = torch.device(device)
+        # The schedule arrays go to the kernels as they are: a file written by a build with another
+        # ABI (item layout, chunking rule) would give wrong sums or out-of-range reads — refuse it.
+        if meta.get("abi_version") != _native.GCN_ABI_VERSION:
+            raise cache.CacheFormatError(
+                f"{path}: written by ABI version {meta.get('abi_version')}, this build is "
+                f"{_native.GCN_ABI_VERSION}: rebuild the cache (CSRGraph.save)")
 
         def dev_t(a):
             import warnings
@@ -376,7 +361,40 @@ class CSRGraph:
                 warnings.simplefilter("ignore", UserWarning)
                 return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+        def check_schedule(prefix, n_rows):
+            """The stored schedule must be THE schedule of the stored row pointer: structural
+            checks always; with verify=True the host planner re-derives it (0.2 s at 10^7 rows)
+            and every array must match."""
+            rp = arr[prefix + "rowptr"]
+            sched = {k: arr[prefix + k] for k in cls._PLAN_KEYS}
+            ni, nc, nl = sched["items"].size // 2, sched["chunk_row"].size, sched["long_row"].size
+            bad = None
+            if rp.size != n_rows + 1 or sched["items"].size % 2:
+                bad = "row pointer / item array size"
+            elif sched["chunk_e0"].size != nc or sched["long_chunk0"].size != nl + 1:
+                bad = "chunk / long-row array sizes"
+            elif nl and (int(sched["long_chunk0"][0]) != 0 or int(sched["long_chunk0"][-1]) != nc):
+                bad = "long_chunk0 does not span the chunks"
+            elif not nl and nc:
+                bad = "chunks without long rows"
+            elif ni and (int(sched["items"].min()) < 0 or int(sched["items"].max()) > n_rows):
+                bad = "item row range"
+            elif nc and (int(sched["chunk_row"].min()) < 0 or int(sched["chunk_row"].max()) >= n_rows
+                         or int(sched["chunk_e0"].min()) < 0 or int(sched["chunk_e0"].max()) >= int(rp[-1])):
+                bad = "chunk row / entry range"
+            elif nl and (int(sched["long_row"].min()) < 0 or int(sched["long_row"].max()) >= n_rows):
+                bad = "long row range"
+            if bad is None and verify:
+                want = host_schedule(rp, n_rows, meta["item_cost"], meta["long_thresh"])
+                for k in cls._PLAN_KEYS:
+                    if not np.array_equal(np.asarray(sched[k]), want[k]):
+                        bad = f"`{k}` is not the schedule of the stored row pointer"
+                        break
+            if bad is not None:
+                raise cache.CacheFormatError(f"{path}: inconsistent schedule ({prefix}{bad})")
+
         def get(prefix, shape):
+            check_schedule(prefix, shape[0])
             g = cls(dev_t(arr[prefix + "rowptr"]), dev_t(arr[prefix + "col"]),
                     dev_t(arr[prefix + "val"]), shape, item_cost=meta["item_cost"],
                     long_thresh=meta["long_thresh"], validate=verify)
@@ -392,8 +410,6 @@ class CSRGraph:
                        "long_row": padded("long_row", torch.int32),
                        "long_chunk0": dev_t(arr[prefix + "long_chunk0"]),
                        "n_items": ni, "n_chunks": nc, "n_long": nl}
-            if g._keep["long_chunk0"].numel() != nl + 1:
-                raise cache.CacheFormatError(f"{path}: inconsistent schedule arrays")
             return g
         g = get("a.", (meta["n_rows"], meta["n_cols"]))
         if g.nnz != meta["nnz"]:
@@ -411,6 +427,34 @@ class CSRGraph:
 
     def __repr__(self):
         return f"CSRGraph(shape={self.shape}, nnz={self.nnz}, device={self.device})"
+
+
+def host_schedule(rp_host, n_rows, item_cost, long_thresh):
+    """Launch schedule of a HOST row pointer (int32 / int64 numpy array) from the host planner
+    `gcn_plan_{count,fill}_host`: the arrays of struct gcn_csr_plan as numpy arrays."""
+    L = _native.lib()
+    rp_host = np.ascontiguousarray(rp_host)
+    if rp_host.dtype not in (np.int32, np.int64) or rp_host.size != n_rows + 1:
+        raise RuntimeError("host_schedule: rowptr must be int32 / int64 with n_rows + 1 entries")
+    is64 = int(rp_host.dtype == np.int64)
+    ni, nc, nl = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _native.check(L.gcn_plan_count_host(rp_host.ctypes.data, is64, n_rows, item_cost,
+                                        long_thresh, ctypes.byref(ni), ctypes.byref(nc),
+                                        ctypes.byref(nl)), "gcn_plan_count_host")
+    ni, nc, nl = ni.value, nc.value, nl.value
+    items = np.empty(max(2 * ni, 1), np.int32)
+    chunk_row = np.empty(max(nc, 1), np.int32)
+    chunk_e0 = np.empty(max(nc, 1), np.int64)
+    long_row = np.empty(max(nl, 1), np.int32)
+    long_chunk0 = np.empty(nl + 1, np.int32)
+    _native.check(L.gcn_plan_fill_host(rp_host.ctypes.data, is64, n_rows, item_cost,
+                                       long_thresh, items.ctypes.data, ni,
+                                       chunk_row.ctypes.data, chunk_e0.ctypes.data, nc,
+                                       long_row.ctypes.data, long_chunk0.ctypes.data, nl),
+                  "gcn_plan_fill_host")
+    return {"items": items[:2 * ni], "chunk_row": chunk_row[:nc], "chunk_e0": chunk_e0[:nc],
+            "long_row": long_row[:nl], "long_chunk0": long_chunk0,
+            "n_items": ni, "n_chunks": nc, "n_long": nl}
 
 
 _ADJ_CACHE_ATTR = "_pygcn_amd_graph"

@@ -14,6 +14,7 @@ if not __package__:   # flat import, the reference's convention (`from models im
     from layers import GraphConvolution
 else:
     from pygcn_amd.layers import GraphConvolution
+from pygcn_amd.tuning import ROWGRAD_MIN_ROWS  # noqa: E402
 
 
 class GCN(nn.Module):
@@ -35,13 +36,22 @@ class GCN(nn.Module):
         validation on other rows, as upstream's --fastmode uses it."""
         if rows is not None:
             return self._forward_rows(x, adj, rows, keep_full)
-        # F.dropout(F.relu(gc1(x, adj)), p, training) with ReLU and dropout fused into the SpMM store
-        x = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
-        # F.log_softmax(gc2(x, adj), dim=1) — in the SpMM's store when a row fits one wavefront
-        # (dim=1 for the reference's [N, C]; the last dim if batched)
-        out = self.gc2(x, adj, log_softmax=True)
+        graph = self._one_node_graph(x, adj)
+        if graph is not None:
+            # the whole model as ONE autograd node (pygcn_amd/fused.py): its backward pass takes the
+            # row-restricted route when the caller selected `output[idx_train]` (upstream's next
+            # line, pygcn/train.py:153) and the full-height route for a loss over all vertices
+            fused, _, _, dropout_seed_for = self._imports()
+            p = self.dropout if self.training else 0.0
+            out = fused.gcn2_full(x, self.gc1, self.gc2, graph, p, dropout_seed_for(x) if p > 0.0 else 0)
+        else:
+            # F.dropout(F.relu(gc1(x, adj)), p, training) with ReLU and dropout fused into the SpMM store
+            h = self.gc1(x, adj, relu=True, dropout=self.dropout if self.training else 0.0)
+            # F.log_softmax(gc2(x, adj), dim=1) — in the SpMM's store when a row fits one wavefront
+            # (dim=1 for the reference's [N, C]; the last dim if batched)
+            out = self.gc2(h, adj, log_softmax=True)
         if (self.training and out.requires_grad and out.dim() == 2 and out.is_cuda
-                and out.shape[0] >= 16384             # (below that an epoch is launch-bound either way)
+                and out.shape[0] >= ROWGRAD_MIN_ROWS     # (pygcn_amd/tuning.py)
                 and type(adj).__name__ != "ShardedGraph"):
             # upstream's next line is `output[idx_train]`: let that selection hand the backward pass
             # the rows instead of a dense gradient (pygcn_amd/rowgrad.py)
@@ -49,22 +59,32 @@ class GCN(nn.Module):
             out = out.as_subclass(RowSelectable)
         return out
 
-    def _forward_rows(self, x, adj, rows, keep_full):
+    @staticmethod
+    def _imports():
+        import pygcn_amd.fused as fused
+        from pygcn_amd.graph import CSRGraph, as_graph
+        from pygcn_amd.spmm import dropout_seed_for
+        return fused, CSRGraph, as_graph, dropout_seed_for
+
+    def _one_node_graph(self, x, adj):
+        """The prepared graph handle if the one-node path covers this call, else None (sharded /
+        dense adjacency, batched input, class counts the fused log_softmax does not take)."""
         import torch
-        if __package__:
-            from pygcn_amd import fused
-            from pygcn_amd.graph import CSRGraph, as_graph
-            from pygcn_amd.spmm import dropout_seed_for
-        else:
-            import pygcn_amd.fused as fused
-            from pygcn_amd.graph import CSRGraph, as_graph
-            from pygcn_amd.spmm import dropout_seed_for
+        fused, CSRGraph, as_graph, _ = self._imports()
         graph = adj
         if isinstance(adj, torch.Tensor) and adj.layout in (torch.sparse_coo, torch.sparse_csr) \
                 and adj.is_cuda:
             graph = as_graph(adj)
-        if isinstance(graph, CSRGraph) and fused.fusable(self.gc2.weight.dtype, self.gc2.out_features,
-                                                         graph, x):
+        if (isinstance(graph, CSRGraph) and isinstance(x, torch.Tensor) and x.dim() == 2
+                and x.dtype == self.gc1.weight.dtype and self.gc1.weight.is_cuda
+                and fused.fusable(self.gc2.weight.dtype, self.gc2.out_features, graph, x)):
+            return graph
+        return None
+
+    def _forward_rows(self, x, adj, rows, keep_full):
+        graph = self._one_node_graph(x, adj)
+        if graph is not None:
+            fused, _, _, dropout_seed_for = self._imports()
             p = self.dropout if self.training else 0.0
             seed = dropout_seed_for(x) if p > 0.0 else 0
             out, full = fused.gcn2_rows(x, self.gc1, self.gc2, graph, rows, p, seed, keep_full)

@@ -56,6 +56,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
+from . import tuning
 from .graph import CSRGraph
 from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, pack_row_flags, spmm_csr,
                    unpack_row_flags)
@@ -518,7 +519,9 @@ class ShardedGraph:
         partial result in through its identity entries and applies the epilogue) follows the
         arrival — see split_block()."""
         ev = self._tic(local)
-        kw = {"dropout_p": dropout_p, "seed": seed + self.rank} if dropout_p > 0.0 else {}
+        # (the same seed on every rank + the block's first global row in the counter: the masks of
+        #  the single-GPU run, whatever the number of ranks)
+        kw = {"dropout_p": dropout_p, "seed": seed, "row_base": self.r0} if dropout_p > 0.0 else {}
         if log_softmax:          # (in the store of the launch that completes the rows)
             kw["log_softmax"] = True
         tag = "bwd_local" if transpose else "fwd_local"
@@ -627,7 +630,7 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         ctx.relu = bool(relu)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         ev = sg._tic(x_local)
-        kw = {"dropout_p": dropout_p, "seed": seed + sg.rank} if dropout_p > 0.0 else {}
+        kw = {"dropout_p": dropout_p, "seed": seed, "row_base": sg.r0} if dropout_p > 0.0 else {}
         # REASSOCIATED where the GEMM kernel can carry the epilogue (256 -> 256 fp32, HIP):
         #     out_r = epilogue((Â_r · [X_r ; X_halo]) · W + b)
         # — the same local product at the same width, then ONE GEMM over the rank's own rows (the
@@ -685,7 +688,7 @@ class ShardedInputLayerFunction(torch.autograd.Function):
             # of the fused backward pass the product computes only the others (c_select) and the
             # GEMM runs over them (a purely local decision: no collective depends on it)
             sparse = (hint is not None and sg._hinted_product
-                      and int(hint[1].item()) * 3 < grad_pre.shape[0])
+                      and tuning.below(int(hint[1].item()), grad_pre.shape[0], tuning.SPARSE_GEMM_MAX_SHARE))
             ev = sg._tic(grad_pre)
             z = sg._spmm(sg.A, x_local, tag="bwd_local", B2=x_halo,   # this rank's rows of Â · X
                          **({"c_select": hint[0]} if sparse else {}))
@@ -721,19 +724,39 @@ class ShardedGCN(torch.nn.Module):
         from . import sharded_fused as sf
         from .spmm import dropout_seed_for
         if not sf.fusable(sg, self.model, x_local):
-            return self.model(x_local, sg)[rows]
-        key = (rows.data_ptr(), rows.numel(), rows._version, rows.dtype)
-        hit = self._row_sets.get(key)
-        if hit is None:
-            if len(self._row_sets) >= 4:
-                self._row_sets.clear()
-            hit = self._row_sets[key] = (sf.ShardedRowSets(sg, rows), rows)      # (keeps `rows` alive)
+            return self.model(x_local, sg)[rows.rows_user if isinstance(rows, sf.ShardedRowSets) else rows]
+        if isinstance(rows, sf.ShardedRowSets):
+            rs = rows                              # prepared handle: nothing collective, no lookup
+        else:
+            # A tensor: look it up by identity — and make the build decision SYMMETRIC.  The
+            # constructor is collective; if one rank re-created its index tensor (a miss) while
+            # the others still hit, the collectives would not match and the job would hang.  One
+            # tiny all-reduce of a "must rebuild" flag per call (a host synchronisation: training
+            # loops should pass the handle of prepare_rows() instead — bench.py does).
+            from .fused import rows_key
+            key = rows_key(rows)
+            hit = self._row_sets.get(key)
+            miss = torch.tensor([0 if hit is not None else 1], dtype=torch.int32, device=x_local.device)
+            dist.all_reduce(miss, op=dist.ReduceOp.MAX, group=sg.group)
+            if int(miss.item()):
+                if len(self._row_sets) >= 4:
+                    self._row_sets.clear()
+                hit = self._row_sets[key] = (sf.ShardedRowSets(sg, rows), rows)  # (keeps `rows` alive)
+            rs = hit[0]
         m = self.model
         p = m.dropout if m.training else 0.0
         seed = dropout_seed_for(x_local) if p > 0.0 else 0
-        return sf.ShardedGCN2RowsFunction.apply(sg, hit[0], x_local, sg.constant_halo(x_local),
+        return sf.ShardedGCN2RowsFunction.apply(sg, rs, x_local, sg.constant_halo(x_local),
                                                 m.gc1.weight, m.gc1.bias, m.gc2.weight, m.gc2.bias,
                                                 float(p), seed)
+
+    def prepare_rows(self, rows_local):
+        """COLLECTIVE: the static backward structure for the loss rows of every rank (local row
+        ids of the caller's block; may be empty) — pygcn_amd/sharded_fused.py.  Pass the returned
+        handle as `rows=`: the forward call then involves no cache lookup, no flag exchange and
+        no host synchronisation."""
+        from . import sharded_fused as sf
+        return sf.ShardedRowSets(self.sg, rows_local)
 
     def nll_loss(self, logp_local, labels_local, idx_local=None):
         """This rank's share of the global-mean NLL over the (optionally index-selected) nodes of

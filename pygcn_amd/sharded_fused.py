@@ -121,7 +121,7 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
         if f32:
             ctx.z_bound = sg.A.inf_norm() * sg.constant_absmax(x_local) * 1.0001
             h_bound = torch.zeros(1, dtype=torch.float32, device=x_local.device)
-        kw = {"dropout_p": dropout_p, "seed": seed + sg.rank} if dropout_p > 0.0 else {}
+        kw = {"dropout_p": dropout_p, "seed": seed, "row_base": sg.r0} if dropout_p > 0.0 else {}
         h1 = _spmm.layer_gemm(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, **kw)
         if h1 is None:
             raise RuntimeError("sharded one-node path: the layer GEMM declined the operands")

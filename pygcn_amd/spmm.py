@@ -10,8 +10,9 @@ fallback exists: non-HIP tensors or a missing library raise.
 """
 import torch
 
-from . import _native
+from . import _native, tuning
 from .graph import CSRGraph, _require_cuda, as_graph
+from .tuning import K_SPLIT, MIN_ROWS, REASSOC_MAX_WIDTH_RATIO      # (dispatch thresholds: one table)
 
 _DTYPES = {torch.float32: _native.GCN_DTYPE_F32, torch.bfloat16: _native.GCN_DTYPE_BF16}
 
@@ -39,7 +40,7 @@ def set_timing_records(records):
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
              b_hint=None, B2=None, c_flags=None, log_softmax=False, c_select=None,
-             skip_zero_rows=False):
+             skip_zero_rows=False, row_base=0):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
@@ -56,7 +57,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     `c_select`: optional int32 bitmap [ceil(n_rows/32)] over the OUTPUT rows: rows whose bit is
     clear are not wanted and may be left unwritten (gcn_epilogue.c_row_select).
     `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
-    (hipGraph replays draw a fresh mask if the graph updates the tensor, see dropout_seed_for)."""
+    (hipGraph replays draw a fresh mask if the graph updates the tensor, see dropout_seed_for).
+    `row_base`: added to the row index in the dropout counter — a row-block shard passes the global
+    index of its first row and draws the masks of the single-GPU run."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -118,7 +121,7 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  c_flags.data_ptr() if c_flags is not None else None,
                                  int(bool(log_softmax)), seed_dev,
                                  c_select.data_ptr() if c_select is not None else None,
-                                 int(bool(skip_zero_rows) and c_flags is not None))
+                                 int(bool(skip_zero_rows) and c_flags is not None), int(row_base))
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)
@@ -204,6 +207,36 @@ def backward_with_colsum(grad_out, out=None, scale=1.0, log_softmax=False, skip_
     _native.check(rc, "gcn_log_softmax_backward_colsum" if log_softmax
                   else "gcn_relu_dropout_backward_colsum")
     return grad_pre, colsum.to(grad_out.dtype), hint
+
+
+def nll_log_softmax_backward(logp, target, coef):
+    """(grad_pre, column sums) for the gradient of a mean NLL loss over ALL rows of log-probabilities
+    `logp` [n, F] (C-ABI gcn_nll_log_softmax_backward_colsum): grad_pre = coef·(onehot(target) −
+    exp(logp)) and the bias gradient's column sums in ONE sweep that reads logp and the labels and
+    writes grad_pre — the [n, F] loss gradient (one non-zero per row) is never materialised.
+    `target` int64 [n] with entries in [0, F), `coef` DEVICE float32 [1].  None when the shape is
+    outside the kernel's envelope (a row must sit in one wavefront)."""
+    _require_cuda(logp, "logp")
+    L = _native.lib()
+    if (logp.dtype not in _DTYPES or logp.dim() != 2 or not logp.is_contiguous() or logp.shape[0] == 0
+            or target.dtype != torch.int64 or target.numel() != logp.shape[0] or not target.is_contiguous()
+            or target.device != logp.device or coef.dtype != torch.float32 or coef.numel() != 1
+            or coef.device != logp.device
+            or L.gcn_bwd_colsum_workspace_bytes(logp.shape[0], logp.shape[1], _DTYPES[logp.dtype]) == 0
+            or logp.shape[1] // (16 // logp.element_size()) > 64):
+        return None
+    n, F = logp.shape
+    grad_pre = torch.empty_like(logp)
+    colsum = torch.empty(F, dtype=torch.float32, device=logp.device)
+    ws_bytes = L.gcn_bwd_colsum_workspace_bytes(n, F, _DTYPES[logp.dtype])
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=logp.device)
+    with torch.cuda.device(logp.device):
+        rc = L.gcn_nll_log_softmax_backward_colsum(
+            _DTYPES[logp.dtype], target.data_ptr(), coef.data_ptr(), logp.data_ptr(),
+            grad_pre.data_ptr(), colsum.data_ptr(), n, F, ws.data_ptr(), ws_bytes,
+            torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_nll_log_softmax_backward_colsum")
+    return grad_pre, colsum.to(logp.dtype)
 
 
 def pack_row_flags(nz):
@@ -337,7 +370,7 @@ class SpMMFunction(torch.autograd.Function):
 
 
 def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0,
-               bias=None, relu=False, dropout_p=0.0, seed=0, mask_rows=None):
+               bias=None, relu=False, dropout_p=0.0, seed=0, mask_rows=None, row_base=0):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -407,7 +440,8 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
                     mask_src.data_ptr() if mask_src is not None else None,
                     mask_src.stride(0) if mask_src is not None else 0, float(mask_scale),
-                    mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None)
+                    mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None,
+                    int(row_base))
             rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0),
                                          rows.data_ptr() if rows is not None else None,
                                          W.data_ptr(), W.stride(0),
@@ -415,6 +449,9 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                                          y_absmax.data_ptr() if y_absmax is not None else None,
                                          ep, ws.data_ptr(), ws_bytes, stream)
             _native.check(rc, "gcn_gemm_xw256_f32_h2")
+            if _bound_check and y_absmax is not None and not bool(torch.isfinite(y_absmax).all()):
+                raise RuntimeError("gemm_xw256: non-finite output — x_bound was smaller than max|X| (the "
+                                   "fp16 parts overflowed) or the operands hold inf / NaN")
             return Y
         ws_bytes = L.gcn_gemm_xw256_workspace_bytes()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
@@ -426,7 +463,7 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     return Y
 
 
-def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0):
+def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0, row_base=0):
     """X[M,K] · W[K,N] for bf16 storage through the streaming MFMA kernel (C-ABI gcn_gemm_xw_bf16;
     (K, N) in {(128,128), (128,256), (256,128)} — config C5's layers are 128 -> 128).
     `bias` / `relu` / `dropout_p` / `seed`: the layer's FORWARD epilogue on the fp32 accumulators
@@ -451,7 +488,8 @@ def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0):
         if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
             seed_dev, seed = seed.data_ptr(), 0
         ep = _native.GcnGemmEpilogue(bias32.data_ptr() if bias32 is not None else None, int(bool(relu)),
-                                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev, None, 0, 1.0, None)
+                                     float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev, None, 0, 1.0, None,
+                                     int(row_base))
     Y = torch.empty((X.shape[0], N), dtype=torch.bfloat16, device=X.device)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     with torch.cuda.device(X.device):
@@ -477,11 +515,13 @@ def layer_gemm_reassociable(x, weight, bias):
     return False
 
 
-def layer_gemm(z, weight, z_bound=None, y_absmax=None, bias=None, relu=False, dropout_p=0.0, seed=0):
+def layer_gemm(z, weight, z_bound=None, y_absmax=None, bias=None, relu=False, dropout_p=0.0, seed=0,
+               row_base=0):
     """epilogue(z·W + b) through the kernel layer_gemm_reassociable() promised (None if it declines)."""
     if z.dtype == torch.float32:
-        return gemm_xw256(z, weight, z_bound, y_absmax, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
-    return gemm_bf16(z, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
+        return gemm_xw256(z, weight, z_bound, y_absmax, bias=bias, relu=relu, dropout_p=dropout_p,
+                          seed=seed, row_base=row_base)
+    return gemm_bf16(z, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed, row_base=row_base)
 
 
 _identity_lists = {}
@@ -564,6 +604,18 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
 
 
 _gemm_scheme = "h2"
+_bound_check = False
+
+
+def set_bound_check(enabled):
+    """DEBUG switch: after every scaled GEMM that reports max|Y|, read it on the host (a stream
+    synchronisation) and raise if it is not finite.  The kernels never hide an overflow — a bound
+    that was too small makes y_absmax inf / NaN (its integer maximum keeps those patterns), and a
+    consumer scaled by a non-finite bound stores NaN — so a wrong bound ends in a NaN loss, not in
+    plausible numbers; this switch names the first launch that overflowed."""
+    global _bound_check
+    _bound_check = bool(enabled)
+
 
 
 def set_gemm_scheme(name):
@@ -580,16 +632,20 @@ _absmax_cache = {}
 
 def absmax_cached(t):
     """max|t| as a DEVICE float tensor [1], computed once per (tensor object, version): for operands
-    that stay constant across steps (the feature matrix).  The cache holds a weak reference to the
-    tensor OBJECT — a new tensor that happens to reuse the storage address of a freed one can
-    never inherit its bound (a bound that is too small would overflow the fp16 parts)."""
+    that stay constant across steps (the feature matrix).  A few entries per device (an eval-mode
+    forward pass sees every layer's input as "constant": they must not evict each other), each
+    holding a weak reference to the tensor OBJECT — a new tensor that happens to reuse the storage
+    address of a freed one can never inherit its bound (a bound that is too small would overflow
+    the fp16 parts)."""
     import weakref
     key = t.device.index if t.device.index is not None else -1
-    hit = _absmax_cache.get(key)
-    if hit is None or hit[0]() is not t or hit[1] != t._version:
-        val = torch.linalg.vector_norm(t.detach(), ord=float("inf")).float().reshape(1)
-        hit = _absmax_cache[key] = (weakref.ref(t), t._version, val)
-    return hit[2]
+    live = [e for e in _absmax_cache.get(key, []) if e[0]() is not None]
+    for ref, version, val in live:
+        if ref() is t and version == t._version:
+            return val
+    val = torch.linalg.vector_norm(t.detach(), ord=float("inf")).float().reshape(1)
+    _absmax_cache[key] = live[-3:] + [(weakref.ref(t), t._version, val)]
+    return val
 
 
 _absmax_known = {}
@@ -626,8 +682,6 @@ def _dense_forward(input, weight, x_bound=None, y_absmax=None):
     return out
 
 
-K_SPLIT = 128          # slabs of the weight-gradient reduction
-MIN_ROWS = 1 << 17     # below this the plain GEMMs are launch-bound anyway
 
 
 def _weight_grad(input, grad, a_bound=None, g_bound=None):
@@ -713,14 +767,16 @@ class DenseMMFunction(torch.autograd.Function):
         return _dense_grads(input, weight, grad, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
 
 
-_row_compaction = True
+_row_compaction = False
 
 
 def set_row_compaction(enabled):
-    """Row compaction of the layer's gradient GEMMs reads two device counters on the host (two
-    stream synchronisations per layer backward, only for graphs of >= MIN_ROWS vertices).  Switch
-    it off to keep the backward pass free of synchronisation (it is skipped by itself while the
-    stream is being captured into a hipGraph)."""
+    """OPT-IN (default off since round 3): row compaction of the layer-by-layer path's gradient
+    GEMMs reads two device counters on the host (two stream synchronisations per layer backward,
+    only for graphs of >= MIN_ROWS vertices).  The model-level paths need none of it — a loss on
+    selected rows reaches the layers as a structural RowGrad (pygcn_amd/rowgrad.py, fused.py) — so
+    by default no backward pass synchronises with the host; a caller that composes bare layers
+    under a row-sparse dense gradient can switch this on (never active during hipGraph capture)."""
     global _row_compaction
     _row_compaction = bool(enabled)
 
@@ -733,7 +789,7 @@ def _hint_will_be_used(B, nz_rows):
     v = 16 // B.element_size()
     wide = (F % v == 0 and F // v > 32 and B.stride(1) == 1 and B.data_ptr() % 16 == 0
             and (B.stride(0) * B.element_size()) % 16 == 0)
-    return nz_rows * 4 < n * 3 if wide else nz_rows * 8 < n
+    return tuning.below(nz_rows, n, tuning.HINT_WIDE_MAX_SHARE if wide else tuning.HINT_NARROW_MAX_SHARE)
 
 
 class GraphConvFunction(torch.autograd.Function):
@@ -905,7 +961,7 @@ class GraphConvFunction(torch.autograd.Function):
             z, grad_w = input, None
             if sync_ok and hint is not None:
                 nz_rows = int(hint[1].item())
-                if nz_rows * 3 < grad_pre.shape[0]:      # row-sparse gradient: the listed rows only
+                if tuning.below(nz_rows, grad_pre.shape[0], tuning.SPARSE_GEMM_MAX_SHARE):   # the listed rows only
                     rows = torch.nonzero(unpack_row_flags(hint[0], grad_pre.shape[0])).squeeze(1)
                     lst = padded_row_list(rows)
                     grad_w = weight_grad_rows(z, grad_pre, lst, lst, ctx.z_bound, None, n_list=nz_rows)
@@ -927,8 +983,8 @@ class GraphConvFunction(torch.autograd.Function):
         compact = sync_ok and hint is not None
         unwritten = compact and (ctx.relu or ctx.log_softmax)   # grad_pre: flagged rows only
         nz_rows = int(hint[1].item()) if compact else None
-        if (compact and not need_in and nz_rows * 3 < grad_pre.shape[0]
-                and input.shape[1] <= 2 * grad_pre.shape[1]):
+        if (compact and not need_in and tuning.below(nz_rows, grad_pre.shape[0], tuning.SPARSE_GEMM_MAX_SHARE)
+                and input.shape[1] <= REASSOC_MAX_WIDTH_RATIO * grad_pre.shape[1]):
             # First layer (its input needs no gradient) under a row-sparse grad_pre:
             #     grad_W = inputᵀ · (Aᵀ · grad_pre) = (A · input)ᵀ · grad_pre,
             # and only the rows of A · input that meet a non-zero row of grad_pre take part: a
@@ -947,7 +1003,7 @@ class GraphConvFunction(torch.autograd.Function):
             # the product below would gather every row: give the unwritten ones their zeros
             keep = unpack_row_flags(hint[0], grad_pre.shape[0])[:, None]
             grad_pre = torch.where(keep, grad_pre, torch.zeros_like(grad_pre[:1]))
-        if compact and nz_rows * 8 < grad_pre.shape[0]:
+        if compact and tuning.below(nz_rows, grad_pre.shape[0], tuning.SPARSE_FLAGS_MAX_SHARE):
             c_flags = torch.zeros(n, dtype=torch.uint8, device=grad_pre.device)
         # with the flags requested, all-zero rows of the product are not even written: the GEMMs
         # below read the flagged rows only
@@ -957,7 +1013,7 @@ class GraphConvFunction(torch.autograd.Function):
                             if c_flags is not None else None)
         if c_flags is not None:
             rows = torch.nonzero(c_flags).squeeze(1)
-            if rows.numel() * 3 >= n:     # too dense to pay: make the skipped rows real zeros
+            if not tuning.below(rows.numel(), n, tuning.SPARSE_GEMM_MAX_SHARE):     # too dense to pay: real zeros
                 rows = None
                 grad_sup = torch.where(c_flags.bool()[:, None], grad_sup, torch.zeros_like(grad_sup[:1]))
         grad_in, grad_w = _dense_grads(input, weight, grad_sup, need_in, need_w, rows)

@@ -13,7 +13,10 @@ import scipy.sparse as sp
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_CORA = os.path.join(os.path.dirname(_HERE), "tests", "golden", "cora_graph.npz")
+# the re-indexed pairs of the reference's data/cora/cora.cites (a data file; upstream ships its
+# dataset inside the repository too) — the package's own copy, byte-identical to the golden fixture
+# tests/golden/cora_graph.npz that tests/golden/make_golden.py writes
+DEFAULT_CORA = os.path.join(_HERE, "data", "cora_graph.npz")
 
 
 def encode_onehot(labels):

@@ -1,0 +1,67 @@
+"""`python bench.py --gpus N` with NO launcher (the shape of the driver's single-GPU command with
+another N) must start its own ranks, print ONE JSON line from rank 0 and pass a rank's failure on
+as a non-zero exit status — never hang, never exec-replace a process that has touched the GPU."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=ROOT)
+    return r, time.time() - t0
+
+
+def test_launcher_passes_a_failing_rank_on_cpu():
+    """No GPU here: every rank stops at `bench.py needs MI355X GPUs` — the launcher must come back
+    with a non-zero status (and must not have tried the GPU itself)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check")
+    r, dt = _run(["--gpus", "2", "--rehearsal", "--config", "tiny", "--steps", "1", "--warmup", "0"], 300)
+    assert r.returncode != 0
+    assert "needs MI355X" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert dt < 240
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    r, _ = _run(["--gpus", "2", "--rehearsal", "--config", "c3", "--steps", "2", "--warmup", "1",
+                 "--no-extras"], 900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1
+    for key in ("spmm_only_gedges", "spmm_plus_exchange_gedges", "exchange_bytes_received_per_rank_max",
+                "roofline", "loss_check"):
+        assert key in line, key
+    assert line["exchange_bytes_received_per_rank_max"]["fwd_dense"] > 0
+    # the same problem at every world size: the single-GPU run must print the same eval loss
+    r1, _ = _run(["--gpus", "1", "--config", "c3", "--steps", "1", "--warmup", "0", "--no-extras",
+                  "--no-cpu-baseline"], 900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = line["loss_check"]["value"], one["loss_check"]["value"]
+    assert abs(a - b) <= 2e-5 * abs(b), (a, b)
+    assert line["config"]["nnz"] == one["config"]["nnz"]
+
+
+@pytest.mark.gpu
+def test_bench_launcher_reports_a_dead_rank():
+    r, dt = _run(["--gpus", "2", "--rehearsal", "--config", "tiny", "--steps", "1", "--warmup", "0",
+                  "--fail-rank", "1"], 600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert dt < 500

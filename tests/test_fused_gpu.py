@@ -68,9 +68,12 @@ def test_cora_step_through_the_one_node_path(oracle, dev, poison):
     torch.manual_seed(42)
     model = GCN(1433, 16, 7, dropout=0.0).to(dev)
     _check(model, x, adj.to(dev), a, gin.cora_labels(), idx_train.numpy(), oracle)
+    # ... and against G2, the same step captured from the imported reference layer (seed-42
+    # parameters = G1, same features / labels / idx_train): all four parameter gradients
     g2 = load_golden("g2_cora_step.npz")
-    assert_normwise(model.gc1.weight.grad.cpu(), g2["grad_gc1_weight"], 2e-5, "G2 grad_gc1_weight") \
-        if "grad_gc1_weight" in g2.files else None
+    for mod, name in (("gc1", "weight"), ("gc1", "bias"), ("gc2", "weight"), ("gc2", "bias")):
+        assert_normwise(getattr(getattr(model, mod), name).grad.cpu(), g2[f"{mod}_{name}_grad"], 2e-5,
+                        f"G2 {mod}_{name}_grad")
 
 
 @pytest.mark.parametrize("fin,hid,ncls,share", [(256, 256, 256, 0.05), (48, 64, 16, 0.3), (256, 256, 64, 0.9),
@@ -229,10 +232,10 @@ def test_upstream_lines_take_the_row_sparse_route(oracle, dev, poison):
     torch.manual_seed(5)
     model = GCN(256, 256, 256, dropout=0.0).to(dev)
     model.train()
+    import pygcn_amd.fused as Fz
     seen = []
-    orig = S.GraphConvFunction._backward_rows
-    S.GraphConvFunction._backward_rows = staticmethod(
-        lambda ctx, grad: (seen.append(type(grad).__name__), orig(ctx, grad))[1])
+    orig = Fz._gcn2_backward_rows
+    Fz._gcn2_backward_rows = lambda ctx, *a, **k: (seen.append("rows"), orig(ctx, *a, **k))[1]
     try:
         out = model(x, g)
         assert isinstance(out, RowSelectable) and not isinstance(out[idx], RowSelectable)
@@ -240,8 +243,8 @@ def test_upstream_lines_take_the_row_sparse_route(oracle, dev, poison):
         loss = torch.nn.functional.nll_loss(out[idx], labels[idx])
         loss.backward()
     finally:
-        S.GraphConvFunction._backward_rows = orig
-    assert seen == ["RowGrad", "RowGrad"]                                     # both layers took it
+        Fz._gcn2_backward_rows = orig
+    assert seen == ["rows"]                              # the model's one node took the row route
     got = {k: p.grad.clone() for k, p in model.named_parameters()}
     p = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     ref_loss, _, grads, _ = oracle.gcn2_loss_backward(x.cpu().numpy(), a, p, labels_np, idx_np)
@@ -270,3 +273,146 @@ def test_upstream_lines_take_the_row_sparse_route(oracle, dev, poison):
         assert_normwise(both[k].cpu(), q.grad.cpu().numpy(), 5e-5, "two consumers: " + k)
     rg = RowGrad(torch.tensor([2, 0, 2], device=dev), torch.ones(3, 4, device=dev), 5)
     assert torch.equal(rg.dense(), torch.tensor([[1.] * 4, [0.] * 4, [2.] * 4, [0.] * 4, [0.] * 4], device=dev))
+    # bare layers composed by hand (no model-level node): each layer's own node takes the RowGrad
+    seen = []
+    orig = S.GraphConvFunction._backward_rows
+    S.GraphConvFunction._backward_rows = staticmethod(
+        lambda ctx, grad: (seen.append(type(grad).__name__), orig(ctx, grad))[1])
+    try:
+        model.zero_grad(set_to_none=True)
+        h = model.gc1(x, g, relu=True)
+        out = model.gc2(h, g, log_softmax=True).as_subclass(RowSelectable)
+        torch.nn.functional.nll_loss(out[idx], labels[idx]).backward()
+    finally:
+        S.GraphConvFunction._backward_rows = orig
+    assert seen == ["RowGrad", "RowGrad"]                                     # both layers took it
+    for k, q in model.named_parameters():
+        assert_normwise(q.grad.cpu(), got[k].cpu().numpy(), 5e-5, "layer-by-layer rows route: " + k)
+
+
+def _oracle_step(oracle, model, x, a, labels_np, idx_np):
+    p = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    return oracle.gcn2_loss_backward(x.detach().float().cpu().numpy(), a, p, labels_np, idx_np)
+
+
+@pytest.mark.parametrize("fin,hid,ncls", [(256, 256, 256), (200, 256, 40), (128, 128, 128), (48, 64, 16),
+                                          (256, 256, 64)])
+def test_dense_loss_step_matches_oracle(oracle, dev, poison, fin, hid, ncls):
+    """A loss over ALL vertices (the fork's live loss reduces over every node, pygcn/train.py:151-155)
+    through the model's one node, `_gcn2_backward_dense`: the structural mean-NLL gradient
+    (pygcn_amd.functional.nll_loss -> NLLGrad -> gcn_nll_log_softmax_backward_colsum), torch's
+    F.nll_loss (a dense gradient) and the layer-by-layer path — all against the oracle, at the
+    bench's shape and at shapes that take every fallback of the dispatch (a non-reassociable first
+    layer 200 -> 256, a class count 40 / 16 inside one wavefront, fp32 128 -> 128 without a
+    hand-written GEMM, 48 -> 64)."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.functional import NLLGrad, nll_loss
+    from pygcn_amd.utils import rmat_graph
+    import pygcn_amd.fused as Fz
+    n = 30000
+    rowptr, col, val = rmat_graph(n, 300000, seed=31, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, fin), 9)).to(dev)
+    labels_np = np.random.default_rng(fin).integers(0, ncls, n)
+    labels = torch.from_numpy(labels_np).to(dev)
+    torch.manual_seed(3)
+    model = GCN(fin, hid, ncls, dropout=0.0).to(dev)
+    model.train()
+    ref_loss, fw, grads, _ = _oracle_step(oracle, model, x, a, labels_np, np.arange(n))
+    seen = []
+    orig = Fz._gcn2_backward_dense
+    Fz._gcn2_backward_dense = lambda ctx, x_, w1, w2, h1, logp, grad, needs: (
+        seen.append(type(grad).__name__), orig(ctx, x_, w1, w2, h1, logp, grad, needs))[1]
+    try:
+        for route in ("structural", "dense"):
+            model.zero_grad(set_to_none=True)
+            out = model(x, g)
+            loss = nll_loss(out, labels) if route == "structural" else torch.nn.functional.nll_loss(out, labels)
+            loss.backward()
+            assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss)
+            assert_normwise(out.detach().cpu(), fw["logp"], TOL, route + ": log-probabilities")
+            for k, v in grads.items():
+                mod, name = k.split(".")
+                got = getattr(getattr(model, mod), name).grad
+                assert torch.isfinite(got).all(), k
+                assert_normwise(got.cpu(), v, 2e-5, f"{route} route: {k}.grad")
+    finally:
+        Fz._gcn2_backward_dense = orig
+    assert seen == ["NLLGrad", "Tensor"]
+    # NLLGrad is an ordinary gradient for everybody else
+    lp = torch.randn(50, 8, device=dev).log_softmax(1).requires_grad_(True)
+    t = torch.randint(0, 8, (50,), device=dev)
+    nll_loss(lp * 1.0, t).backward()
+    g1 = lp.grad.clone()
+    lp.grad = None
+    torch.nn.functional.nll_loss(lp * 1.0, t).backward()
+    assert torch.allclose(g1, lp.grad, rtol=1e-6, atol=0)
+    ng = NLLGrad(t, torch.full((1,), -0.02, device=dev), (50, 8), torch.float32)
+    assert torch.equal(ng.dense().nonzero()[:, 1], t) and abs(ng.dense().sum().item() + 1.0) < 1e-6
+
+
+def test_mean_over_nodes_loss_through_the_one_node_path(oracle, dev):
+    """The fork's live loss (pygcn/train.py:151-155): `compressed = torch.mean(gcn_output, axis=0)`,
+    a small head, an MSE — every row of the gradient is non-zero and identical.  One node vs the
+    layer-by-layer path vs torch's CPU autograd on the same dense arithmetic in float64."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.utils import rmat_graph
+    n, F = 20000, 256
+    rowptr, col, val = rmat_graph(n, 200000, seed=41, device="cpu")
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, F), 10)).to(dev)
+    torch.manual_seed(11)
+    model = GCN(F, F, F, dropout=0.0).to(dev)
+    head = torch.nn.Linear(F, 1).to(dev)
+    model.train()
+
+    def loss_of(out):
+        return torch.nn.functional.mse_loss(head(out.mean(0)).squeeze(), torch.tensor(0.25, device=out.device))
+    loss_of(model(x, g)).backward()
+    one = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    h = model.gc1(x, g, relu=True)
+    loss_of(model.gc2(h, g, log_softmax=True)).backward()
+    for k, p in model.named_parameters():
+        assert_normwise(one[k].cpu(), p.grad.cpu().numpy(), 5e-5, "one node vs layers: " + k)
+    # float64 CPU autograd of the same function (torch.spmm = the reference's call)
+    A = torch.sparse_csr_tensor(rowptr.long(), col.long(), val.double(), (n, n))
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.state_dict().items()}
+    xd = x.double().cpu()
+    h1 = torch.relu(torch.sparse.mm(A, xd @ P["gc1.weight"]) + P["gc1.bias"])
+    lp = torch.log_softmax(torch.sparse.mm(A, h1 @ P["gc2.weight"]) + P["gc2.bias"], 1)
+    hw, hb = head.weight.detach().double().cpu(), head.bias.detach().double().cpu()
+    ref = torch.nn.functional.mse_loss((lp.mean(0) @ hw.t() + hb).squeeze(), torch.tensor(0.25, dtype=torch.float64))
+    ref.backward()
+    for k in one:
+        assert_normwise(one[k].cpu(), P[k].grad.numpy(), 2e-5, "vs float64 autograd: " + k)
+
+
+def test_row_sets_of_aliasing_index_views_do_not_collide(oracle, dev):
+    """idx[:100] and idx[0:200:2] share storage pointer, length and version counter —
+    the row-set cache must tell them apart (stride / offset are part of the key)."""
+    from pygcn_amd import GCN, CSRGraph, fused
+    from pygcn_amd.utils import rmat_graph
+    n = 20000
+    rowptr, col, val = rmat_graph(n, 200000, seed=51, device="cpu")
+    a = oracle.CSR(rowptr.numpy().astype(np.int64), col.numpy(), val.numpy(), (n, n))
+    g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
+    x = torch.from_numpy(gin.dense((n, 256), 12)).to(dev)
+    labels_np = np.random.default_rng(8).integers(0, 256, n)
+    labels = torch.from_numpy(labels_np).to(dev)
+    base = torch.from_numpy(np.random.default_rng(9).permutation(n)[:3000]).to(dev)
+    v1, v2 = base[:1500], base[0:3000:2]
+    assert v1.data_ptr() == v2.data_ptr() and v1.numel() == v2.numel() and v1._version == v2._version
+    assert fused.rows_key(v1) != fused.rows_key(v2)
+    torch.manual_seed(6)
+    model = GCN(256, 256, 256, dropout=0.0).to(dev)
+    model.train()
+    for view in (v1, v2, v1):
+        model.zero_grad(set_to_none=True)
+        out = model(x, g)
+        torch.nn.functional.nll_loss(out[view], labels[view]).backward()
+        _, _, grads, _ = _oracle_step(oracle, model, x, a, labels_np, view.cpu().numpy())
+        for k, v in grads.items():
+            mod, name = k.split(".")
+            assert_normwise(getattr(getattr(model, mod), name).grad.cpu(), v, 2e-5, f"aliasing views: {k}")

@@ -340,3 +340,38 @@ def test_bf16_gemm_forward_epilogue(dev, K, N, p):
     b_only = gemm_bf16(X, W, bias=bias)
     ref = X.double() @ W.double() + bias.double()
     assert bool(((b_only.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5 * float(ref.abs().max())).all())
+
+
+def test_a_bound_that_is_too_small_is_never_silent(dev):
+    """the scaled fp16 GEMM trusts the caller's upper bound of max|X|.  A bound that is
+    too small overflows the fp16 parts; that must surface — y_absmax becomes non-finite (its
+    integer maximum keeps inf / NaN patterns), a consumer scaled by such a bound stores NaN, and
+    the debug switch names the launch — never plausible-looking numbers."""
+    import pygcn_amd.spmm as S
+    from pygcn_amd.spmm import gemm_xw256, weight_grad_rows
+    torch.manual_seed(0)
+    M = 4096
+    X = torch.randn(M, 256, device=dev)
+    X[17, 3] = 5000.0                                   # the element the bound forgets
+    W = torch.randn(256, 256, device=dev) * 0.06
+    good, bad = X.abs().max().reshape(1), torch.full((1,), 0.05, device=dev)   # 5000 / 0.05 >> 2^17... and >> 4
+    ymax = torch.zeros(1, device=dev)
+    Y = gemm_xw256(X, W, x_bound=good, y_absmax=ymax)
+    assert torch.isfinite(Y).all() and torch.isfinite(ymax).all()
+    assert abs(ymax.item() - Y.abs().max().item()) <= 1e-6 * ymax.item()
+    ymax_bad = torch.zeros(1, device=dev)
+    Yb = gemm_xw256(X, W, x_bound=bad, y_absmax=ymax_bad)
+    assert not torch.isfinite(Yb).all()                 # the overflow is visible in the output ...
+    assert not torch.isfinite(ymax_bad).all()           # ... and in the reported maximum
+    # downstream: a GEMM / weight gradient scaled by the non-finite bound stores NaN, not zeros
+    Z = gemm_xw256(Y, W, x_bound=ymax_bad)
+    assert torch.isnan(Z).all()
+    gw = weight_grad_rows(Y, Y, a_bound=ymax_bad, g_bound=ymax)
+    assert torch.isnan(gw).all()
+    S.set_bound_check(True)
+    try:
+        with pytest.raises(RuntimeError, match="x_bound was smaller"):
+            gemm_xw256(X, W, x_bound=bad, y_absmax=torch.zeros(1, device=dev))
+        gemm_xw256(X, W, x_bound=good, y_absmax=torch.zeros(1, device=dev))
+    finally:
+        S.set_bound_check(False)

@@ -95,7 +95,7 @@ def test_planner_rejects_bad_input():
 def test_spmm_argument_errors_without_gpu():
     """Argument validation happens before any launch, so it is testable on CPU."""
     L = _native.lib()
-    assert ctypes.sizeof(_native.GcnEpilogue) == 104
+    assert ctypes.sizeof(_native.GcnEpilogue) == 112      # (ABI 22: + drop_row_base)
     assert L.gcn_spmm_csr(None, 0, None, 0, None, 0, 4, None, 0, None, 0, None) == -1
     p = _native.GcnCsrPlan()
     p.n_rows, p.n_cols, p.nnz = 4, 4, 0
@@ -344,3 +344,17 @@ def test_row_sparse_gradient_carrier_mechanics():
     rg = RowGrad(torch.tensor([2, 0, 2]), torch.ones(3, 2), 4)
     assert tuple(rg.shape) == (4, 2) and torch.equal(rg.dense(), torch.tensor([[1., 1.], [0., 0.], [2., 2.], [0., 0.]]))
     assert torch.equal(rg + 1, rg.dense() + 1)
+
+
+def test_package_ships_its_own_cora_fixture():
+    """The package must not reach into tests/: its default dataset is its own copy of the edge-list
+    fixture — byte-identical to the golden one the generating script writes."""
+    import pygcn_amd.utils as U
+    assert os.path.dirname(U.DEFAULT_CORA).endswith(os.path.join("pygcn_amd", "data"))
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cora_graph.npz")
+    assert open(U.DEFAULT_CORA, "rb").read() == open(golden, "rb").read()
+    pkg = os.path.dirname(os.path.abspath(U.__file__))
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert '"tests"' not in src and "from tests" not in src and "import tests" not in src, name

@@ -177,3 +177,50 @@ def test_cache_file_round_trip_without_replanning(dev, tmp_path, monkeypatch):
             assert torch.equal(a._keep[k][:m], b._keep[k][:m]), k
     assert torch.equal(spmm_csr(h, B), want) and torch.equal(spmm_csr(h.t(), B), want_t)   # bitwise
     assert real is _native.lib().gcn_csr_transpose_device
+
+
+def test_cache_file_with_a_foreign_or_garbled_schedule_is_rejected(dev, tmp_path):
+    """the schedule of a cache file goes to the kernels as it is — a file from another
+    ABI version, or one whose (CRC-consistent) schedule is not the schedule of its row pointer,
+    must be refused instead of producing wrong sums / out-of-range reads."""
+    from pygcn_amd import CSRGraph, _native, cache, spmm_csr
+    from pygcn_amd.utils import rmat_graph
+    n = 20_000
+    rowptr, col, val = rmat_graph(n, 400_000, seed=3, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    path = str(tmp_path / "g.pygcn")
+    g.save(path)
+    B = torch.randn(n, 64, device=dev)
+    assert torch.equal(spmm_csr(CSRGraph.load(path, device=dev), B), spmm_csr(g, B))
+    meta, arr = cache.read_file(path, mmap=False)
+    assert meta["abi_version"] == _native.GCN_ABI_VERSION
+
+    def rewritten(name, meta_edit=None, **edits):
+        m = dict(meta, **(meta_edit or {}))
+        a = {k: np.array(v) for k, v in arr.items()}
+        for k, fn in edits.items():
+            a[k.replace("__", ".")] = fn(a[k.replace("__", ".")])
+        q = str(tmp_path / name)
+        cache.write_file(q, m, a)          # (sections get fresh, VALID checksums)
+        return q
+    with pytest.raises(cache.CacheFormatError, match="ABI version"):
+        CSRGraph.load(rewritten("abi", {"abi_version": _native.GCN_ABI_VERSION - 1}), device=dev)
+    with pytest.raises(cache.CacheFormatError, match="ABI version"):
+        CSRGraph.load(rewritten("abi2", {"abi_version": None}), device=dev, verify=False)
+
+    def shift_items(a):
+        b = a.copy()
+        b[3] += 1                           # second item now ends one row late
+        return b
+    with pytest.raises(cache.CacheFormatError, match="schedule"):
+        CSRGraph.load(rewritten("items", a__items=shift_items), device=dev)
+    with pytest.raises(cache.CacheFormatError, match="schedule"):
+        CSRGraph.load(rewritten("chunk", t__chunk_e0=lambda a: a[::-1].copy()), device=dev)
+    with pytest.raises(cache.CacheFormatError, match="schedule"):       # another planner setting
+        CSRGraph.load(rewritten("cost", {"item_cost": 32}), device=dev)
+    # structural damage is caught even with verify=False (no CRC pass, no planner run)
+    with pytest.raises(cache.CacheFormatError, match="schedule"):
+        CSRGraph.load(rewritten("range", a__items=lambda a: np.where(np.arange(a.size) == 1, n + 7, a)
+                                .astype(a.dtype)), device=dev, verify=False)
+    with pytest.raises(cache.CacheFormatError, match="schedule"):
+        CSRGraph.load(rewritten("short", a__long_chunk0=lambda a: a[:-1].copy()), device=dev, verify=False)

@@ -30,7 +30,7 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
     from pygcn_amd.sharded import ShardedGCN, ShardedGraph
     from pygcn_amd.utils import rmat_graph
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pygcn_amd._rehearsal import install_host_staging
+    from tools.rehearsal import install_host_staging
     install_host_staging()      # gloo moves host memory: stage device tensors through the host
     try:
         dev = torch.device("cuda:0")
@@ -154,7 +154,7 @@ def _bf16_worker(rank, world, port, n, n_edges, out_dir):
     from pygcn_amd.sharded import ShardedGCN, ShardedGraph
     from pygcn_amd.utils import rmat_graph
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pygcn_amd._rehearsal import install_host_staging
+    from tools.rehearsal import install_host_staging
     install_host_staging()
     try:
         dev = torch.device("cuda:0")

@@ -327,32 +327,12 @@ def test_batched_samples_match_per_sample_loop(oracle, dev):
     assert_normwise(loop.detach().cpu(), y.detach().cpu().numpy(), TOL, "loop vs batched")
 
 
-def _philox_keep(seed, rows, F, p):
-    """numpy restatement of the kernel's dropout mask: element (row, f) is kept iff word f&3 of
-    Philox4x32-10(counter=(row_lo, row_hi, f>>2, 0), key=(seed_lo, seed_hi)) >= p * 2^32."""
-    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
-    mask32 = np.uint64(0xFFFFFFFF)
-    nq = (F + 3) // 4
-    r = np.repeat(np.asarray(rows, np.uint64), nq)
-    q = np.tile(np.arange(nq, dtype=np.uint64), len(rows))
-    c = [r & mask32, r >> np.uint64(32), q, np.zeros_like(q)]
-    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-    for _ in range(10):
-        p0, p1 = np.uint64(M0) * c[0], np.uint64(M1) * c[2]
-        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask32, p1 >> np.uint64(32), p1 & mask32
-        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
-        k0, k1 = (k0 + np.uint64(W0)) & mask32, (k1 + np.uint64(W1)) & mask32
-    words = np.stack(c, axis=1).reshape(len(rows), nq * 4)[:, :F]
-    thresh = min(4294967295, int(np.float32(p).astype(np.float64) * 4294967296.0))
-    return words >= np.uint64(max(thresh, 1))
-
-
 @pytest.mark.parametrize("F,dtype", [(256, torch.float32), (16, torch.float32), (7, torch.float32),
                                      (300, torch.float32), (128, torch.bfloat16)])
 def test_fused_relu_dropout_epilogue_matches_philox_restatement(oracle, dev, F, dtype):
     """Row f1: bias + ReLU + inverted dropout inside the store.  The mask is a pure function of
-    (seed, row, f): restated in numpy above and compared exactly, for every kernel variant
-    (wide, narrow vector, narrow scalar, bf16, long rows)."""
+    (seed, row, f): restated in numpy (oracle.dropout_keep) and compared exactly, for every kernel
+    variant (wide, narrow vector, narrow scalar, bf16, long rows)."""
     from pygcn_amd import spmm_csr
     n = 1500
     a = _skewed_csr(oracle, n, n, 6, seed=5, hubs=((2, 900), (700, 300)), empties=60)
@@ -363,7 +343,7 @@ def test_fused_relu_dropout_epilogue_matches_philox_restatement(oracle, dev, F, 
     plain = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True).float().cpu().numpy()
     out = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True, dropout_p=p,
                    seed=seed).float().cpu().numpy()
-    keep = _philox_keep(seed, np.arange(n), F, p)
+    keep = oracle.dropout_keep(seed, np.arange(n), F, p)
     assert 0.47 < keep.mean() < 0.53
     np.testing.assert_array_equal(out[~keep], 0.0)
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-6
@@ -1169,3 +1149,29 @@ def test_colsum_pass_refuses_row_bitmap_for_rows_wider_than_a_wavefront(dev):
     assert rc == 0
     want = torch.where(o > 0, g, torch.zeros_like(g))
     assert torch.equal(res, want) and torch.allclose(colsum, want.sum(0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("F,dtype,p", [(256, torch.float32, 0.5), (64, torch.float32, 0.1), (128, torch.bfloat16, 0.3)])
+def test_dropout_row_base_gives_a_shard_the_masks_of_the_whole(oracle, dev, F, dtype, p):
+    """ABI 22: `drop_row_base` is added to the row index in the dropout counter — a row-block shard
+    that passes its first global row draws exactly the masks the single-GPU run draws for those
+    rows (SpMM epilogue and both GEMM epilogues; oracle.dropout_keep restates the function)."""
+    from pygcn_amd import CSRGraph, spmm_csr
+    from pygcn_amd.spmm import gemm_bf16, gemm_xw256
+    n, base, seed = 700, 123456789012, 0xC0FFEE1234
+    eye = CSRGraph(torch.arange(n + 1, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
+                   torch.ones(n, device=dev), (n, n))
+    ones = torch.ones(n, F, device=dev).to(dtype)
+    got = spmm_csr(eye, ones, relu=True, dropout_p=p, seed=seed, row_base=base).float().cpu().numpy() != 0
+    want = oracle.dropout_keep(seed, np.arange(n), F, p, row_base=base)
+    np.testing.assert_array_equal(got, want)
+    assert abs(want.mean() - (1 - p)) < 0.02
+    assert not np.array_equal(want, oracle.dropout_keep(seed, np.arange(n), F, p))
+    if dtype == torch.float32 and F == 256:
+        W = torch.eye(256, device=dev)
+        y = gemm_xw256(ones, W, x_bound=torch.ones(1, device=dev), relu=True, dropout_p=p, seed=seed, row_base=base)
+        np.testing.assert_array_equal(y.cpu().numpy() != 0, want)
+    if dtype == torch.bfloat16:
+        W = torch.eye(128, device=dev).bfloat16()
+        y = gemm_bf16(ones, W, relu=True, dropout_p=p, seed=seed, row_base=base)
+        np.testing.assert_array_equal(y.float().cpu().numpy() != 0, want)

@@ -2,7 +2,8 @@
 
 A gpurun box has a single MI355X and RCCL refuses two ranks on one device, so the N > 1 code path
 (partition, halo exchange, pipelined product, gradient all-reduce) is rehearsed with all ranks
-sharing cuda:0 and the collectives going over gloo, staged through host memory.  Used by
+sharing cuda:0 and the collectives going over gloo, staged through host memory.  Lives outside the
+package on purpose (test scaffolding: it patches torch.distributed process-wide); used by
 `bench.py --rehearsal` and tests/test_sharded_gpu.py only."""
 import torch
 import torch.distributed as dist
@@ -10,7 +11,7 @@ import torch.distributed as dist
 
 def install_host_staging():
     """Route the collectives pygcn_amd.sharded uses through host copies (gloo moves host memory)."""
-    from . import sharded as sh
+    from pygcn_amd import sharded as sh
     real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
     real_begin, real_end = sh._p2p_begin, sh._p2p_end
 
