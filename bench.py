@@ -129,11 +129,15 @@ def host_cpu_info():
 def cpu_baseline_child(path):
     """Runs in a CHILD process (a crash in a CPU library must not lose the GPU result): times
     the reference-side CPU products on the sample saved by the parent; prints JSON lines (the
-    last complete one wins)."""
+    last complete one wins).  Legs, SURVEY §8(d): the reference's call `torch.spmm(adj, support)`
+    (pygcn/layers.py:34) forward, and forward + backward (`out.backward(G)`: autograd's
+    `adj.t() @ grad` of pygcn/train.py:157), on (i) the COO int64 layout the reference builds
+    (pygcn/utils.py:407-414) and (ii) CSR (MKL — the best CPU case); plus the oracle's OpenMP port."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     z = np.load(path)
     rp, c, v, n, F = z["rowptr"], z["col"], z["val"], int(z["n"]), int(z["F"])
     budget_rows, nnz_s = len(rp) - 1, int(rp[-1])
+    whole = bool(z["whole"])
     model, phys, logical = host_cpu_info()
     threads = max(1, min(phys, len(os.sched_getaffinity(0))))
     torch.set_num_threads(threads)
@@ -141,22 +145,32 @@ def cpu_baseline_child(path):
     # torch.randn of 2.56e9 elements alone would take longer than the whole baseline)
     blk = torch.randn(65536, F, generator=torch.Generator().manual_seed(44))
     Bt = blk.repeat((n + 65535) // 65536, 1)[:n].contiguous()
+    Gt = blk.repeat((budget_rows + 65535) // 65536, 1)[:budget_rows].contiguous()
 
-    def best(fn, reps=3):
+    def best(fn, reps=3, budget_s=25.0):
+        """min / median over up to `reps` runs after one warm-up, stopping early once the leg has
+        used its time budget (the whole baseline must stay within a few minutes)."""
+        t0 = time.perf_counter()
         fn()
         ts = []
         for _ in range(reps):
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             fn()
-            ts.append(time.perf_counter() - t0)
-        return min(ts), float(np.median(ts))
+            ts.append(time.perf_counter() - t1)
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return min(ts), float(np.median(ts)), len(ts)
 
-    sample = (f"first {budget_rows} rows ({nnz_s} stored entries) of the same normalized adjacency "
-              f"x full dense operand [{n},{F}] fp32; min of 3 after 1 warm-up")
+    sample = ((f"the WHOLE normalized adjacency ({budget_rows} rows, {nnz_s} stored entries)" if whole else
+               f"first {budget_rows} rows ({nnz_s} stored entries: a 1/{max(1, round(n / budget_rows))} row "
+               f"block) of the same normalized adjacency") +
+              f" x full dense operand [{n},{F}] fp32 (a 65 536-row random block tiled to {n} rows — "
+              f"values do not affect the timing); backward seed G [{budget_rows},{F}] likewise; min of up "
+              f"to 3 runs after 1 warm-up per leg")
     # (i) the reference's literal call on its own layout: torch.spmm(COO int64, dense)
     rows = np.repeat(np.arange(budget_rows, dtype=np.int64), np.diff(rp))
     coo = torch.sparse_coo_tensor(np.vstack([rows, c.astype(np.int64)]), v, (budget_rows, n))
-    t_coo, t_coo_med = best(lambda: torch.spmm(coo, Bt))
+    t_coo, t_coo_med, _ = best(lambda: torch.spmm(coo, Bt))
     out = {"value": round(nnz_s / t_coo / 1e9, 5), "unit": "GEdge/s", "cores": threads,
            "kind": "reference",
            "what": "torch.spmm(adj, dense) — the reference's call (pygcn/layers.py:34) on the COO "
@@ -166,15 +180,33 @@ def cpu_baseline_child(path):
            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical,
            "torch_threads": torch.get_num_threads(), "torch_version": torch.__version__}
     print(json.dumps(out), flush=True)
+
+    def fwd_bwd(A, parts_b, parts_g):
+        for bp, gp in zip(parts_b, parts_g):
+            bp.grad = None
+            torch.spmm(A, bp).backward(gp)
+    # forward + backward through autograd, as `loss.backward()` runs it (pygcn/train.py:157):
+    # grad_support = adj.t() @ grad_output.  bwd_gedges = entries / (t_fwd+bwd - t_fwd).
+    Bg = Bt.clone().requires_grad_(True)
+    t_fb, _, k = best(lambda: fwd_bwd(coo, [Bg], [Gt]), reps=2, budget_s=40.0)
+    out["fwd_plus_bwd_s"] = round(t_fb, 4)
+    out["fwd_s"] = round(t_coo, 4)
+    out["bwd_gedges"] = round(nnz_s / max(t_fb - t_coo, 1e-9) / 1e9, 5)
+    out["fwd_plus_bwd_gedges"] = round(2 * nnz_s / t_fb / 1e9, 5)
+    out["bwd_note"] = ("out = torch.spmm(adj_coo, B.requires_grad_()); out.backward(G) — autograd's "
+                       f"transpose product (pygcn/train.py:157); min of {k} run(s) after 1 warm-up; "
+                       "bwd_gedges = entries / (t(fwd+bwd) - t(fwd))")
+    del Bg
+    print(json.dumps(out), flush=True)
     # (ii) the oracle's OpenMP CSR port (test infrastructure; timed here as the "port" baseline)
     import gcn_oracle
     B = Bt.numpy()
-    t_port, _ = best(lambda: gcn_oracle.spmm_csr(rp, c, v, B))
+    t_port, _, _ = best(lambda: gcn_oracle.spmm_csr(rp, c, v, B))
     out["oracle_port_csr_gedges"] = round(nnz_s / t_port / 1e9, 5)
     out["oracle_port_threads"] = gcn_oracle.lib().oracle_num_threads()
     print(json.dumps(out), flush=True)
     # (iii) the same torch call on CSR (MKL sparse BLAS — the best CPU case).  MKL's 32-bit
-    # interface crashes when the dense operand has >= 2^31 elements (seen: SIGSEGV at n*F =
+    # interface crashes when a dense operand has >= 2^31 elements (seen: SIGSEGV at n*F =
     # 2.56e9), so the operand is multiplied in column panels of < 2^31 elements each
     csr = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(c.astype(np.int64)),
                                   torch.from_numpy(v), size=(budget_rows, n))
@@ -183,9 +215,15 @@ def cpu_baseline_child(path):
         panels *= 2
     w = F // panels
     parts = [Bt[:, i * w:(i + 1) * w].contiguous() for i in range(panels)]
-    t_csr, _ = best(lambda: [torch.spmm(csr, p) for p in parts], reps=2)
+    t_csr, _, _ = best(lambda: [torch.spmm(csr, p) for p in parts], reps=2)
     out["torch_spmm_csr_gedges"] = round(nnz_s / t_csr / 1e9, 5)
     out["torch_spmm_csr_note"] = f"MKL CSR, dense operand in {panels} column panel(s) of {w}"
+    print(json.dumps(out), flush=True)
+    parts_b = [p.clone().requires_grad_(True) for p in parts]
+    parts_g = [Gt[:, i * w:(i + 1) * w].contiguous() for i in range(panels)]
+    t_csr_fb, _, _ = best(lambda: fwd_bwd(csr, parts_b, parts_g), reps=2, budget_s=40.0)
+    out["torch_spmm_csr_bwd_gedges"] = round(nnz_s / max(t_csr_fb - t_csr, 1e-9) / 1e9, 5)
+    out["torch_spmm_csr_fwd_plus_bwd_s"] = round(t_csr_fb, 4)
     print(json.dumps(out), flush=True)
 
 
@@ -198,7 +236,7 @@ def cpu_baseline(rowptr, col, val, n, F, budget_rows):
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "sample.npz")
         np.savez(path, rowptr=rp, col=col[:nnz_s].cpu().numpy(), val=val[:nnz_s].cpu().numpy(),
-                 n=n, F=F)
+                 n=n, F=F, whole=bool(budget_rows >= rowptr.numel() - 1))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path],
                            capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -602,6 +640,22 @@ def main():
                 spmm_mod.set_timing_records(None)
                 extras["ms_per_step_dense_loss"] = None
                 extras["dense_loss_note"] = f"failed: {ex!r}"
+            if dt == "f32":
+                try:       # the same graded epoch with every GEMM on hipBLASLt's exact-fp32 path
+                    spmm_mod.set_gemm_scheme("exact")
+                    restore_snapshot()
+                    epoch()
+
+                    def exact_step():
+                        restore_snapshot()
+                        epoch()
+                    wall, _ = timed(3, exact_step)
+                    extras["ms_per_step_exact_gemm"] = round(wall / 3 * 1e3, 3)
+                except Exception as ex:
+                    extras["ms_per_step_exact_gemm"] = None
+                    extras["exact_gemm_note"] = f"failed: {ex!r}"
+                finally:
+                    spmm_mod.set_gemm_scheme("h2")
             try:
                 restore_snapshot()
                 epoch(reference_call=True)
@@ -671,7 +725,15 @@ def main():
             "ms_per_step_min_max": [round(min(per_step), 3), round(max(per_step), 3)],
             "ms_per_step_median_hip_events": round(float(np.median(per_step)), 3),
             "tolerance_note": "parity contract 1e-5 relative is per step (one forward/backward); "
-                              "a 200-epoch Adam trajectory is gated at 1e-3 (chained fp32 steps)",
+                              "documented exceptions: grad_W / grad_b of a reduction over >= 30 000 "
+                              "vertices 2e-5, agreement between two HIP routes 5e-5, a 200-epoch Adam "
+                              "trajectory 1e-3 (chained fp32 steps)",
+            "gemm_scheme": ("h2: the dense 256x256 products of the epoch (not the SpMM, which is plain fp32 "
+                            "FMA — `value` and `roofline` do not depend on this) run as a power-of-two-"
+                            "scaled two-part fp16 MFMA emulation of fp32 (22-bit significand, 4e-7 "
+                            "normwise vs fp64; pygcn_amd/csrc/gcn_gemm.hip); `ms_per_step_exact_gemm` is "
+                            "the same epoch with every GEMM on hipBLASLt's exact fp32 path "
+                            "(set_gemm_scheme('exact'))") if dt == "f32" else "bf16 MFMA, fp32 accumulate",
             "host_syncs_per_step": syncs,
             "host_syncs_note": "MEASURED on one extra epoch of the timed kind after the timed region "
                                "(torch.cuda.set_sync_debug_mode: every synchronising call warns); the "
@@ -726,8 +788,11 @@ def main():
                                                   "transfers (pipelined dense exchange, rank 0)")
         if world == 1 and not args.no_cpu_baseline:
             try:
+                # the whole graph where it runs in seconds (C3-sized and below), a
+                # 1/8 row block at C4, 1/64 at C5 (bounded CPU work; the sample is named in the line)
+                frac = 1 if nnz <= 20_000_000 else (8 if nnz <= 200_000_000 else 64)
                 line["cpu_baseline"] = cpu_baseline(rowptr, col, val, n, feat,
-                                                    budget_rows=max(1, n // 16))
+                                                    budget_rows=max(1, n // frac))
             except Exception as ex:
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)

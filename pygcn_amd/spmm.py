@@ -390,8 +390,8 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
     product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
     underflow — tests/test_gemm_gpu.py)."""
-    if (X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda or X.dim() != 2
-            or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
+    if (_gemm_scheme == "exact" or X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda
+            or X.dim() != 2 or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
@@ -560,8 +560,8 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     unpadded lists are padded here.  *_bound: DEVICE float [1] upper bounds of max|A|, max|G|
     (computed here by a reduction pass over the listed rows when missing).  None if the operands
     do not fit the kernel (fp32, 256 columns each)."""
-    if (A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda or A.dim() != 2
-            or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
+    if (_gemm_scheme != "h2" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
+            or A.dim() != 2 or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
             or G.stride(1) != 1):
         return None
     if n_list is None:
@@ -619,11 +619,18 @@ def set_bound_check(enabled):
 
 
 def set_gemm_scheme(name):
-    """"h2": use the scaled two-part fp16 kernel wherever a bound of max|X| is known (default);
-    "bf16x3": always the three-part bf16 kernel (no assumption about the data's dynamic range)."""
+    """How the fp32 256 -> 256 GEMMs of the layers are evaluated:
+    "h2" (default): the scaled two-part fp16 MFMA kernels (22-bit significand, 4e-7 normwise vs fp64)
+        wherever a bound of max|X| is known — forward, grad_input, gather-fused weight gradients;
+    "bf16x3": the three-part bf16 kernel for the forward / grad_input GEMMs (no assumption about
+        the data's dynamic range), hipBLASLt for the weight gradients;
+    "exact": no hand-written fp32 GEMM at all — every dense product is `torch.mm` (hipBLASLt's exact
+        fp32 MFMA path, the arithmetic of the reference's `torch.mm(input, self.weight)`,
+        pygcn/layers.py:33) and the layers keep the reference's order Â·(X·W).  The SpMM kernels
+        are the same in all three."""
     global _gemm_scheme
-    if name not in ("h2", "bf16x3"):
-        raise RuntimeError("gemm scheme must be 'h2' or 'bf16x3'")
+    if name not in ("h2", "bf16x3", "exact"):
+        raise RuntimeError("gemm scheme must be 'h2', 'bf16x3' or 'exact'")
     _gemm_scheme = name
 
 

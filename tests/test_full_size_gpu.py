@@ -84,6 +84,23 @@ def test_sampled_rows_against_oracle(c4, oracle):
     assert_normwise(out[rows].cpu(), ref, 1e-5, "sampled rows incl. hubs")
 
 
+def test_sampled_rows_of_the_transpose_product_against_oracle(c4, oracle):
+    """Âᵀ·G with a random G at full size — the backward product of a dense-gradient epoch —
+    against the oracle on >= 3 000 sampled rows of CSR(Âᵀ) incl. its 40 heaviest (the hub COLUMNS
+    of Â: tens of thousands of entries each, the chunked long-row path)."""
+    from pygcn_amd import spmm_csr
+    from _sampling import heavy_and_random_rows, sampled_rows_reference
+    g, n = c4
+    gt = g.t()
+    gen = torch.Generator(device=g.device).manual_seed(18)
+    G = torch.randn(n, 256, generator=gen, device=g.device)
+    out = spmm_csr(gt, G)
+    rows, heaviest = heavy_and_random_rows(gt, 40, 3000, gen)
+    assert heaviest > 20000
+    assert_normwise(out[rows].cpu(), sampled_rows_reference(oracle, gt, G, rows), 1e-5,
+                    "C4 transpose product: sampled rows incl. the heaviest columns")
+
+
 def test_transpose_block_equals_the_full_transpose_product(c4):
     """The [|R2|, |R|] block of Âᵀ the one-node backward pass multiplies (cut from the rows R of
     CSR(Â)) against the full cached CSR(Âᵀ) on an operand that is zero outside R: the same rows,

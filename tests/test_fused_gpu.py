@@ -49,11 +49,13 @@ def _check(model, x, adj_graph, a, labels, idx, oracle, tol_w=2e-5, need_x=False
         assert_normwise(got.cpu(), v, tol_w, k + ".grad")
     if need_x:
         assert_normwise(x.grad.cpu(), extra["grad_x"], TOL, "grad_x")
+    kept = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
     # and it is the same function as the plain call + indexing
     model.zero_grad()
     plain = model(x.detach(), adj_graph)
     loss2 = torch.nn.functional.nll_loss(plain[idx_t], torch.from_numpy(labels).to(dev)[idx_t])
     assert abs(loss2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    return kept
 
 
 def test_cora_step_through_the_one_node_path(oracle, dev, poison):
@@ -67,13 +69,12 @@ def test_cora_step_through_the_one_node_path(oracle, dev, poison):
     x = torch.from_numpy(gin.cora_features()).to(dev)
     torch.manual_seed(42)
     model = GCN(1433, 16, 7, dropout=0.0).to(dev)
-    _check(model, x, adj.to(dev), a, gin.cora_labels(), idx_train.numpy(), oracle)
+    got = _check(model, x, adj.to(dev), a, gin.cora_labels(), idx_train.numpy(), oracle)
     # ... and against G2, the same step captured from the imported reference layer (seed-42
     # parameters = G1, same features / labels / idx_train): all four parameter gradients
     g2 = load_golden("g2_cora_step.npz")
     for mod, name in (("gc1", "weight"), ("gc1", "bias"), ("gc2", "weight"), ("gc2", "bias")):
-        assert_normwise(getattr(getattr(model, mod), name).grad.cpu(), g2[f"{mod}_{name}_grad"], 2e-5,
-                        f"G2 {mod}_{name}_grad")
+        assert_normwise(got[f"{mod}.{name}"].cpu(), g2[f"{mod}_{name}_grad"], 2e-5, f"G2 {mod}_{name}_grad")
 
 
 @pytest.mark.parametrize("fin,hid,ncls,share", [(256, 256, 256, 0.05), (48, 64, 16, 0.3), (256, 256, 64, 0.9),
