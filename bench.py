@@ -427,7 +427,7 @@ def main():
             # a loss over ALL vertices (the fork's live loss reduces over every node, reference
             # pygcn/train.py:151-155): pygcn_amd.functional.nll_loss = F.nll_loss (mean), whose
             # gradient reaches the model's backward pass in structural form (one non-zero per row)
-            loss = nll_loss(fwd_model(x, adj).float(), labels)
+            loss = nll_loss(fwd_model(x, adj), labels)
         else:
             # upstream: F.nll_loss(output[idx_train], labels[idx_train]) (train.py:153) — the model is
             # told which rows the loss reads, so the backward pass runs on the rows that can be

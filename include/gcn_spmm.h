@@ -420,6 +420,19 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
                         const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/*
+ * The same weight gradient for bf16 STORAGE (config C5: 128 -> 128 layers): A [*, K] and G [*, N]
+ * are bf16 (row-major, even leading dimensions, 4-byte aligned), accumulation and the [K, N] result
+ * are fp32; no scaling and no bounds (bf16 has fp32's range).  (K, N) = (128, 128); the workspace
+ * size is 0 for shapes the kernel does not carry (the caller then uses a library GEMM).  Row lists
+ * as for gcn_gemm_atg256_f32 (padded to a multiple of 16 entries with valid indices).
+ * Deterministic.  (ABI 22.)
+ */
+size_t gcn_gemm_atg_bf16_workspace_bytes(int64_t n_list, int64_t K, int64_t N);
+int gcn_gemm_atg_bf16(const void *A, int64_t lda, const int32_t *rows_a, const void *G, int64_t ldg,
+                      const int32_t *rows_g, int64_t n_list, int64_t K, int64_t N, float *out,
+                      int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,8 +224,13 @@ def gcn2_forward(x, adj, p, relu_out=False):
     return {"h1": h1, "a1": a1, "h2": h2, "logp": log_softmax(h2)}
 
 
-def gcn2_loss_backward(x, adj, p, labels, idx, need_grad_x=False):
-    """nll_loss(logp[idx], labels[idx]) and every gradient of it."""
+def gcn2_loss_backward(x, adj, p, labels, idx, need_grad_x=False, relu_mask=None):
+    """nll_loss(logp[idx], labels[idx]) and every gradient of it.  `relu_mask` (bool [n, hidden],
+    optional): the ReLU derivative to use instead of (h1 > 0) — for comparing with an
+    implementation whose pre-activations differ from this one's by rounding: an element within
+    rounding of zero may sit on the other side of the ReLU there, which changes nothing visible in
+    the forward pass (the value is ~0 either way) but switches one term of grad_W1 on or off; the
+    caller asserts that the two masks differ on such elements only."""
     fw = gcn2_forward(x, adj, p)
     logp = fw["logp"]
     n_tr = len(idx)
@@ -235,7 +240,7 @@ def gcn2_loss_backward(x, adj, p, labels, idx, need_grad_x=False):
     # log_softmax backward: g - softmax * sum(g)
     grad_h2 = (grad_logp - np.exp(logp) * grad_logp.sum(1, keepdims=True)).astype(np.float32)
     ga1, gw2, gb2, _ = gc_backward(fw["a1"], p["gc2.weight"], "gc2.bias" in p, adj, grad_h2)
-    grad_h1 = (ga1 * (fw["h1"] > 0)).astype(np.float32)
+    grad_h1 = (ga1 * ((fw["h1"] > 0) if relu_mask is None else relu_mask)).astype(np.float32)
     gx, gw1, gb1, _ = gc_backward(x, p["gc1.weight"], "gc1.bias" in p, adj, grad_h1,
                                   need_grad_x=need_grad_x)
     grads = {"gc1.weight": gw1, "gc2.weight": gw2}

@@ -68,7 +68,8 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_coo_to_csr_device", "gcn_gemm_xw256_h2_workspace_bytes", "gcn_gemm_xw256_f32_h2",
            "gcn_gemm_bf16_workspace_bytes", "gcn_gemm_xw_bf16",
            "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32",
-           "gcn_nll_log_softmax_backward_colsum")
+           "gcn_nll_log_softmax_backward_colsum", "gcn_gemm_atg_bf16_workspace_bytes",
+           "gcn_gemm_atg_bf16")
 
 _lib = None
 
@@ -197,6 +198,13 @@ def lib():
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_gemm_atg_bf16_workspace_bytes.restype = ctypes.c_size_t
+    L.gcn_gemm_atg_bf16_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
+    L.gcn_gemm_atg_bf16.restype = ctypes.c_int
+    L.gcn_gemm_atg_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                    ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_size_t, ctypes.c_void_p]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

@@ -972,6 +972,159 @@ __global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict
     out[(int64_t)(idx >> 8) * ldo + (idx & 255)] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient at bf16 storage (config C5): grad_W[128, 128] = Σ_r A[ra[r], :]ᵀ ⊗ G[rg[r], :]
+// over a LIST of rows, bf16 operands, fp32 accumulation and fp32 result (`inputᵀ · grad_support`,
+// the backward of pygcn/layers.py:33).  One bf16 MFMA per product; the kernel is a stream (512 B of
+// operand rows per listed vertex against 2·128·128 flops), built like gemm_atg256_h2_kernel:
+//
+//   * the reduction runs over the vertices, so an MFMA lane needs 8 consecutive ROWS of one
+//     column.  A wave loads one whole row per instruction — 128 bf16 = 256 contiguous bytes, one
+//     dword (columns 2l, 2l+1) per lane, row address from the list on the scalar unit (the row
+//     gather is free) — 16 rows per step.  v_perm_b32 then packs the low halves of two rows'
+//     dwords (column 2l) and the high halves (column 2l + 1) into the MFMA's k-pairs, and ONE
+//     v_permlane32_swap per register moves rows 8..15 of the low half-wave's columns to the upper
+//     half-wave: four 32-column fragments per step,
+//         tile t, lane (i, h):  column 64·(t & 1) + 2·i + (t >> 1),  k = 8·h + (0..7)
+//     — a permutation of the columns that only decides where a result element is stored;
+//   * waves 0-1 stream A (alternate steps), waves 2-3 stream G; fragments go through LDS
+//     (double-buffered, one barrier per two steps); wave (iw, jw) multiplies the two A tiles
+//     {2iw, 2iw+1} by the two G tiles {2jw, 2jw+1}: a quarter of the 128 x 128 result;
+//   * loads run kAtgBfDepth iterations ahead in a register ring; slabs of the list go to
+//     workgroups, the partial products are added in slab order by atg_reduce_kernel_n
+//     (deterministic, no atomics).  Lists are padded to a multiple of 16 entries with valid
+//     indices; rows past n_list are multiplied as zeros.
+constexpr int kAtgBfDepth = 3;
+constexpr int kAtgBfBuf = 2 * 2 * 4 * kFragBytes;      // [operand 2][step 2][tile 4] fragments = 16 KiB
+
+__global__ __launch_bounds__(256, 2) void gemm_atg128_bf16_kernel(
+    const uint16_t *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
+    const uint16_t *__restrict__ G, int64_t ldg, const int32_t *__restrict__ rg, int64_t n_list,
+    float *__restrict__ partial, int64_t iters_per_wg)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kAtgBfBuf];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int op = wave >> 1, st = wave & 1;              // operand this wave streams; its step parity
+    const int iw = wave & 1, jw = wave >> 1;              // result quarter: A tiles 2iw.., G tiles 2jw..
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int64_t total_steps = (n_list + 15) >> 4;
+    const int64_t total_iters = (total_steps + 1) >> 1;
+    const int64_t i0 = (int64_t)blockIdx.x * iters_per_wg;
+    const int64_t i1 = i0 + iters_per_wg < total_iters ? i0 + iters_per_wg : total_iters;
+    const uint32_t *src = (const uint32_t *)(op ? G : A) + lane;      // dword = columns 2l, 2l + 1
+    const int64_t ld2 = (op ? ldg : lda) >> 1;                         // row pitch in dwords
+    const int32_t *rows = op ? rg : ra;
+
+    uint32_t ring[kAtgBfDepth][16];
+    auto fetch = [&](int64_t it, uint32_t (&v)[16]) {      // loads only
+        const int64_t step = 2 * it + st;
+        if (step < total_steps) {                          // (wave-uniform)
+            const int32_t *idx = rows + step * 16;         // scalar loads
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0u;
+        }
+    };
+    auto publish = [&](int64_t it, uint32_t (&v)[16], unsigned char *buf) {
+        const int64_t step = 2 * it + st;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (step * 16 + k >= n_list) v[k] = 0u;        // (uniform: rows past the end of the list)
+        uint32_t f0[2][4], f1[2][4];                       // [even / odd column][k pair]: rows 0-7, rows 8-15
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f0[0][j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x05040100u);
+            f0[1][j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x07060302u);
+            f1[0][j] = __builtin_amdgcn_perm(v[2 * j + 9], v[2 * j + 8], 0x05040100u);
+            f1[1][j] = __builtin_amdgcn_perm(v[2 * j + 9], v[2 * j + 8], 0x07060302u);
+        }
+        unsigned char *mine = buf + ((op * 2 + st) * 4) * kFragBytes;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // rows 8-15 of the LOW half-wave's columns <-> rows 0-7 of the HIGH half-wave's
+                auto sw = __builtin_amdgcn_permlane32_swap(f0[e][j], f1[e][j], false, false);
+                lo[j] = sw[0];                             // tile 2e    : columns 2i + e
+                hi[j] = sw[1];                             // tile 2e + 1: columns 64 + 2i + e
+            }
+            *(u32x4 *)(mine + ((2 * e + 0) * 64 + lane) * 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            *(u32x4 *)(mine + ((2 * e + 1) * 64 + lane) * 16) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+
+#pragma unroll
+    for (int d = 0; d < kAtgBfDepth; ++d)
+        if (i0 + d < i1) fetch(i0 + d, ring[d]);
+    for (int64_t base = i0; base < i1; base += kAtgBfDepth) {
+#pragma unroll
+        for (int d = 0; d < kAtgBfDepth; ++d) {
+            const int64_t it = base + d;
+            if (it < i1) {                                                   // (uniform over the workgroup)
+                unsigned char *buf = lds + (int)((it - i0) & 1) * kAtgBfBuf;
+                publish(it, ring[d], buf);
+                if (it + kAtgBfDepth < i1) fetch(it + kAtgBfDepth, ring[d]);
+                __syncthreads();
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 Af[2], Gf[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        // physical tile order in LDS is (even-low, even-high, odd-low, odd-high) = t with
+                        // column 64·(t & 1) + 2i + (t >> 1); a wave takes t = 2iw, 2iw + 1 (one parity)
+                        Af[a] = *(const u32x4 *)(buf + (((0 * 2 + s2) * 4 + 2 * iw + a) * 64 + lane) * 16);
+                        Gf[a] = *(const u32x4 *)(buf + (((1 * 2 + s2) * 4 + 2 * jw + a) * 64 + lane) * 16);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) acc[a][b] = mfma(Af[a], Gf[b], acc[a][b]);
+                }
+            }
+        }
+    }
+    // D[i][j] of tile pair (ta, tb): i = (reg & 3) + 8·(reg >> 2) + 4·(lane >> 5), j = lane & 31;
+    // LDS tile index t = 2e + half  ->  column 64·half + 2·idx + e   (e = t >> 1, half = t & 1)
+    float *out = partial + (size_t)blockIdx.x * (128 * 128);
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ta = 2 * iw + a, tb = 2 * jw + b;
+            const int col = 64 * (tb & 1) + 2 * c + (tb >> 1);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int row = 64 * (ta & 1) + 2 * i + (ta >> 1);
+                out[row * 128 + col] = acc[a][b][reg];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void atg_reduce_kernel_n(const float *__restrict__ partial, int n_wg,
+                                                           float *__restrict__ out, int64_t ldo, int N,
+                                                           int elems)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // one output element
+    if (idx >= elems) return;
+    float s = 0.f;
+    for (int w = 0; w < n_wg; ++w) s += partial[(size_t)w * elems + idx];
+    out[(int64_t)(idx / N) * ldo + (idx % N)] = s;
+}
+
+
 }   // namespace
 
 extern "C" {
@@ -1181,6 +1334,51 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
                        (int)n_wg, out, ldo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32 launch");
+    return 0;
+}
+
+static int64_t atg_bf16_wgs(int64_t n_list)
+{
+    const int64_t iters = ((n_list + 15) / 16 + 1) / 2;
+    return std::max<int64_t>(1, std::min<int64_t>(512, (iters + 7) / 8));
+}
+
+size_t gcn_gemm_atg_bf16_workspace_bytes(int64_t n_list, int64_t K, int64_t N)
+{
+    if (K != 128 || N != 128) return 0;
+    if (n_list <= 0) return 256;
+    return (size_t)atg_bf16_wgs(n_list) * (size_t)(128 * 128) * sizeof(float);
+}
+
+int gcn_gemm_atg_bf16(const void *A, int64_t lda, const int32_t *rows_a, const void *G, int64_t ldg,
+                      const int32_t *rows_g, int64_t n_list, int64_t K, int64_t N, float *out,
+                      int64_t ldo, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (K != 128 || N != 128)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg_bf16: (K, N) must be (128, 128)");
+    if (n_list < 0 || lda < K || ldg < N || ldo < N || (lda & 1) || (ldg & 1))
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg_bf16: bad sizes (even leading dimensions >= K, N)");
+    if (out == nullptr) return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg_bf16: NULL output");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_list == 0) {
+        hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)N * 4, (size_t)K, s);
+        return e == hipSuccess ? 0 : gcn_internal_fail_hip((int)e, "gcn_gemm_atg_bf16: memset");
+    }
+    if (A == nullptr || G == nullptr || rows_a == nullptr || rows_g == nullptr || workspace == nullptr)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg_bf16: NULL pointer");
+    if ((((uintptr_t)A) | ((uintptr_t)G)) % 4 != 0)
+        return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_atg_bf16: operands must be 4-byte aligned");
+    if (workspace_bytes < gcn_gemm_atg_bf16_workspace_bytes(n_list, K, N))
+        return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_atg_bf16: workspace too small");
+    const int64_t n_wg = atg_bf16_wgs(n_list);
+    const int64_t iters = ((n_list + 15) / 16 + 1) / 2;
+    const int64_t per = (iters + n_wg - 1) / n_wg;
+    hipLaunchKernelGGL(gemm_atg128_bf16_kernel, dim3((unsigned)n_wg), dim3(256), 0, s, (const uint16_t *)A,
+                       lda, rows_a, (const uint16_t *)G, ldg, rows_g, n_list, (float *)workspace, per);
+    hipLaunchKernelGGL(atg_reduce_kernel_n, dim3(128 * 128 / 256), dim3(256), 0, s,
+                       (const float *)workspace, (int)n_wg, out, ldo, 128, 128 * 128);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_atg_bf16 launch");
     return 0;
 }
 

@@ -40,9 +40,10 @@ class NLLGrad(torch.Tensor):
 
 class _NLLMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_probs, target):
+    def forward(ctx, log_probs, target, structural=False):
         if log_probs.dim() != 2 or target.dim() != 1 or target.shape[0] != log_probs.shape[0]:
             raise RuntimeError("nll_loss: expected log_probs [n, C] and target [n]")
+        ctx.structural = bool(structural)
         ctx.save_for_backward(target)
         ctx.shape, ctx.dtype = log_probs.shape, log_probs.dtype
         picked = log_probs.gather(1, target.view(-1, 1)).float()
@@ -52,14 +53,26 @@ class _NLLMean(torch.autograd.Function):
     def backward(ctx, grad):
         (target,) = ctx.saved_tensors
         n = ctx.shape[0]
-        if grad.is_cuda and n > 0:       # structural form: nothing of size [n, C] is written here
-            return NLLGrad(target, (-grad / n).float().reshape(1), ctx.shape, ctx.dtype), None
+        if ctx.structural and grad.is_cuda and n > 0:   # nothing of size [n, C] is written here
+            return NLLGrad(target, (-grad / n).float().reshape(1), ctx.shape, ctx.dtype), None, None
         g = torch.zeros(ctx.shape, dtype=ctx.dtype, device=grad.device)
         g.scatter_(1, target.view(-1, 1), (-grad / n).to(ctx.dtype).expand(n, 1))
-        return g, None
+        return g, None, None
 
 
 def nll_loss(log_probs, target):
     """Drop-in for `torch.nn.functional.nll_loss(log_probs, target)` (mean over the rows, no class
-    weights, no ignore_index) — the form the reference's training step uses."""
-    return _NLLMean.apply(log_probs, target)
+    weights, no ignore_index) — the form the reference's training step uses.  fp32 or bf16
+    log-probabilities (the loss value is fp32 either way).
+
+    When `log_probs` is the model's own full output (`model(x, adj)` in training mode: a
+    rowgrad.RowSelectable), its gradient travels in STRUCTURAL form (NLLGrad: the label vector and
+    one coefficient) — the only consumer is then the model's autograd node, which declared it can
+    take it; any other tensor gets the ordinary dense gradient."""
+    from .rowgrad import RowSelectable
+    structural = (isinstance(log_probs, RowSelectable) and log_probs.dim() == 2 and log_probs.is_cuda
+                  and log_probs.requires_grad and target.dtype == torch.int64
+                  and target.device == log_probs.device)
+    if isinstance(log_probs, RowSelectable):
+        log_probs = log_probs.as_subclass(torch.Tensor)
+    return _NLLMean.apply(log_probs, target.contiguous(), structural)

@@ -33,3 +33,29 @@ def heavy_and_random_rows(g, n_heavy, n_random, gen):
     rnd = torch.randint(0, g.shape[0], (n_random,), generator=gen, device=g.device)
     ends = torch.tensor([0, g.shape[0] - 1], device=g.device)
     return torch.unique(torch.cat([top, rnd, ends])), int(deg[top].max())
+
+
+def device_relu_mask(oracle, model, x, g, a, tol=1e-5):
+    """The ReLU derivative the DEVICE used for the hidden layer: (h1 > 0) of the layer-level call
+    (the same kernels as inside the model's one-node path; call with dropout 0).  The oracle's
+    pre-activations differ from the device's by fp32 summation order (the device may evaluate the
+    first layer as (Â·X)·W), so an element within rounding of zero can sit on the other side of the
+    ReLU: invisible in the forward pass, but it switches one term of grad_W1 / grad_b1 on or off —
+    over 10⁶ x 256 hidden units a few dozen such terms move a weight gradient by ~1e-3 of its
+    norm.  The derivative of ReLU at 0 is a convention, not arithmetic: the comparison is made
+    well-posed by handing the oracle the device's mask, AFTER asserting that the two masks differ
+    only where the oracle's own pre-activation is within `tol` of zero (relative to the largest).
+    Returns (mask bool [n, hidden] numpy, number of differing elements)."""
+    was = model.training
+    model.eval()
+    with torch.no_grad():
+        h1 = model.gc1(x, g, relu=True)
+    model.train(was)
+    mask = (h1 > 0).cpu().numpy()
+    p = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    pre, _ = oracle.gc_forward(x.detach().float().cpu().numpy(), p["gc1.weight"], p.get("gc1.bias"), a)
+    flips = mask != (pre > 0)
+    if flips.any():
+        assert np.abs(pre[flips]).max() <= tol * np.abs(pre).max(), "masks differ away from the ReLU boundary"
+    assert flips.mean() < 1e-4
+    return mask, int(flips.sum())

@@ -104,3 +104,68 @@ def test_c5_sampled_rows_against_oracle(c5, oracle):
     assert not bad.any(), f"{bad.sum()} of {bad.size} sampled elements off; worst " \
                           f"{(np.abs(got - ref) / (np.abs(ref) + 1e-30)).max():.3e}"
     assert_normwise(got, ref, BF16_ULP, "sampled rows incl. hubs (normwise)")
+
+
+def test_c5_sampled_rows_of_the_transpose_product_against_oracle(c5, oracle):
+    """Âᵀ·G with a random bf16 G at full size against the oracle (fp64 accumulation of the
+    bf16-rounded operand) on >= 3 000 sampled rows of CSR(Âᵀ) incl. its 40 heaviest."""
+    from pygcn_amd import spmm_csr
+    from _sampling import heavy_and_random_rows
+    g = c5
+    gt = g.t()
+    gen = torch.Generator(device=g.device).manual_seed(28)
+    G = torch.randn(N, F, generator=gen, device=g.device).to(torch.bfloat16)
+    out = spmm_csr(gt, G)
+    rows, heaviest = heavy_and_random_rows(gt, 40, 3000, gen)
+    assert rows.numel() >= 3000 and heaviest > 100_000
+    starts, ends = gt.rowptr[rows].long(), gt.rowptr[rows + 1].long()
+    lens = ends - starts
+    idx = torch.repeat_interleave(starts - torch.cumsum(lens, 0) + lens, lens) + torch.arange(
+        int(lens.sum()), device=g.device)
+    cols, vals = gt.col[idx].long(), gt.val[idx]
+    ucols, inv = torch.unique(cols, return_inverse=True)
+    rp = torch.zeros(len(rows) + 1, dtype=torch.int64, device=g.device)
+    torch.cumsum(lens, 0, out=rp[1:])
+    ref = oracle.spmm_csr_f64acc(rp.cpu().numpy(), inv.cpu().numpy().astype(np.int32),
+                                 vals.cpu().numpy(), G[ucols].float().cpu().numpy())
+    got = out[rows].float().cpu().numpy().astype(np.float64)
+    tol = BF16_ULP * np.abs(ref) + 2e-5 * np.abs(ref).max(1, keepdims=True)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{bad.sum()} of {bad.size} sampled elements off"
+    assert_normwise(got, ref, BF16_ULP, "C5 transpose product: sampled rows incl. the heaviest columns")
+
+
+def test_c5_training_step_routes_agree(c5):
+    """One bf16 training step at full C5 size by two routes through the HIP kernels: the one-node
+    `rows=` call and upstream's unchanged lines `model(x, adj)[idx]` (row-sparse gradient into the
+    model's node).  Same forward kernels; the backward passes share the transpose block but reach
+    it differently: loss, selected rows and all parameter gradients must agree (bf16 storage: 2^-6
+    on gradients that passed two layers of bf16 rounding)."""
+    from pygcn_amd import GCN
+    g = c5
+    dev = g.device
+    gen = torch.Generator(device=dev).manual_seed(44)
+    x = torch.randn(N, F, generator=gen, device=dev).to(torch.bfloat16)
+    labels = torch.randint(0, F, (N,), generator=gen, device=dev)
+    idx = torch.arange(N * 140 // 2708, device=dev)
+    torch.manual_seed(42)
+    model = GCN(F, F, F, dropout=0.0).to(dev).to(torch.bfloat16)
+    model.train()
+    out_rows = model(x, g, rows=idx)
+    loss = torch.nn.functional.nll_loss(out_rows.float(), labels[idx])
+    loss.backward()
+    first = {k: p.grad.clone() for k, p in model.named_parameters()}
+    sel = out_rows.detach().clone()
+    model.zero_grad(set_to_none=True)
+    del out_rows
+    full = model(x, g)
+    loss2 = torch.nn.functional.nll_loss(full[idx].float(), labels[idx])
+    loss2.backward()
+    assert torch.equal(full.detach()[idx], sel)
+    assert abs(loss.item() - loss2.item()) <= 1e-6 * abs(loss.item())
+    del full
+    for k, p in model.named_parameters():
+        a, b = first[k].double(), p.grad.double()
+        assert torch.isfinite(a).all() and float(b.abs().max()) > 0
+        err = float((a - b).abs().max())
+        assert err <= 2.0 ** -6 * float(b.abs().max()), f"{k}: {err:.3e} vs {float(b.abs().max()):.3e}"

@@ -825,11 +825,12 @@ def test_model_uses_fused_log_softmax_and_matches_torch(oracle, dev):
         lab = torch.randint(0, nclass, (idx.numel(),), device=dev)
         seen = []
         orig = S.spmm_csr
-        S.spmm_csr = lambda *a_, **k: (seen.append(k.get("log_softmax", False)), orig(*a_, **k))[1]
+        Fz = importlib.import_module("pygcn_amd.fused")        # (the model's one node calls it from there)
+        S.spmm_csr = Fz.spmm_csr = lambda *a_, **k: (seen.append(k.get("log_softmax", False)), orig(*a_, **k))[1]
         try:
             out = model(x, g)
         finally:
-            S.spmm_csr = orig
+            S.spmm_csr = Fz.spmm_csr = orig
         assert any(seen), "the fused log_softmax epilogue was not used"
         torch.nn.functional.nll_loss(out[idx], lab).backward()
         got = [p.grad.clone() for p in model.parameters()]
