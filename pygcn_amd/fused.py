@@ -232,8 +232,9 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
     h1c = None
     if need_w2:
+        # (fp32 256 x 256 with bounds, or bf16 128 x 128: rows of h1 read in place through the list)
         grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, None,
-                                         ctx.h_bound, gs_bound, n_list=rs.n2) if fast else None
+                                         ctx.h_bound, gs_bound, n_list=rs.n2) if (fast or not f32) else None
         if grad_w2 is None:
             h1c = h1.index_select(0, rs.rows2)
             grad_w2 = _weight_grad(h1c, grad_sup2)
@@ -336,7 +337,8 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
     gs_bound = _exact_absmax(grad_sup2) * 1.0001 if f32 else None
     fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
     if need_w2:
-        grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, None, None, ctx.h_bound, gs_bound) if fast else None
+        grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, None, None, ctx.h_bound, gs_bound) \
+            if (fast or not f32) else None
         if grad_w2 is None:
             grad_w2 = _weight_grad(h1, grad_sup2)
     gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
@@ -357,7 +359,7 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
         z = x
         if need_w1:
             grad_w1 = _spmm.weight_grad_rows(z, gpre1, None, None, ctx.z_bound, gpre_bound) \
-                if (fast and z.shape[1] == 256) else None
+                if ((fast and z.shape[1] == 256) or not f32) else None
             if grad_w1 is None:
                 grad_w1 = _weight_grad(z, gpre1)
         if need_x:

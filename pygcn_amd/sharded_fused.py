@@ -167,19 +167,16 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
             grad_sup2 = gp.new_zeros((rs.n2, gp.shape[1]))
         sg._toc(ev, "bwd")
         f32 = dt == torch.float32
-        gs_bound = None
-        if f32:
-            m = torch.linalg.vector_norm(gp, ord=float("inf")).reshape(1) if rs.n_u else gp.new_zeros(1)
-            if halo.shape[0]:
-                m = torch.maximum(m, torch.linalg.vector_norm(halo, ord=float("inf")).reshape(1))
-            gs_bound = sg.At.inf_norm() * m * 1.0001
+        # bound of max|grad_sup2| for the scaled GEMMs: its exact maximum (a compact [|R2_r|, C] tensor)
+        gs_bound = (torch.linalg.vector_norm(grad_sup2, ord=float("inf")).float().reshape(1) * 1.0001
+                    if rs.n2 else grad_sup2.new_zeros(1).float()) if f32 else None
         fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256 \
             and rs.n2 > 0
         grad_w1 = grad_w2 = grad_b1 = None
         h1c = None
         if need_w2:
             grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, rs.rows2_padded, None, ctx.h_bound, gs_bound,
-                                             n_list=rs.n2) if fast else None
+                                             n_list=rs.n2) if (fast or (not f32 and rs.n2 > 0)) else None
             if grad_w2 is None:
                 h1c = h1.index_select(0, rs.rows2)
                 grad_w2 = _weight_grad(h1c, grad_sup2)
@@ -199,7 +196,8 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
             grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])
         if need_w1:
             grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, ctx.z_bound,
-                                             gh_max if f32 else None, n_list=rs.n2) if fast else None
+                                             gh_max if f32 else None, n_list=rs.n2) \
+                if (fast or (not f32 and rs.n2 > 0)) else None
             if grad_w1 is None:
                 grad_w1 = _weight_grad(z.index_select(0, rs.rows2), gpre1)
         return None, None, None, None, grad_w1, grad_b1, grad_w2, grad_b2, None, None

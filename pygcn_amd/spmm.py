@@ -553,14 +553,22 @@ def _identity_list(n, device):
 
 
 def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None):
-    """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] -> [256, 256] through the gather-fused MFMA kernel (C-ABI
-    gcn_gemm_atg256_f32): the weight gradient `inputᵀ · grad_support` over a LIST of rows, without
-    compacting either operand first.  rows_*: int32 device index lists or None (= all rows, in
-    order).  A list may be longer than `n_list` (padding to a multiple of 16, padded_row_list());
-    unpadded lists are padded here.  *_bound: DEVICE float [1] upper bounds of max|A|, max|G|
-    (computed here by a reduction pass over the listed rows when missing).  None if the operands
-    do not fit the kernel (fp32, 256 columns each)."""
-    if (_gemm_scheme != "h2" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
+    """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] through the gather-fused MFMA kernels: the weight gradient
+    `inputᵀ · grad_support` over a LIST of rows, without compacting either operand first.
+    fp32 [*, 256] x [*, 256] (C-ABI gcn_gemm_atg256_f32, scaled two-part fp16 scheme) or bf16
+    storage [*, 128] x [*, 128] (C-ABI gcn_gemm_atg_bf16: fp32 accumulation, result rounded once
+    to bf16).  rows_*: int32 device index lists or None (= all rows, in order).  A list may be
+    longer than `n_list` (padding to a multiple of 16, padded_row_list()); unpadded lists are
+    padded here.  *_bound (fp32 only): DEVICE float [1] upper bounds of max|A|, max|G| (computed
+    here by a reduction pass over the listed rows when missing).  None if the operands do not fit
+    a kernel."""
+    bf16 = A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
+    if bf16:
+        if (not A.is_cuda or A.dim() != 2 or G.dim() != 2 or A.stride(1) != 1 or G.stride(1) != 1
+                or A.stride(0) % 2 or G.stride(0) % 2 or A.data_ptr() % 4 or G.data_ptr() % 4
+                or _native.lib().gcn_gemm_atg_bf16_workspace_bytes(16, A.shape[1], G.shape[1]) == 0):
+            return None
+    elif (_gemm_scheme != "h2" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
             or A.dim() != 2 or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
             or G.stride(1) != 1):
         return None
@@ -571,7 +579,7 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
             raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
         n_list = n_a
     if n_list == 0:
-        return torch.zeros((256, 256), dtype=torch.float32, device=A.device)
+        return torch.zeros((A.shape[1], G.shape[1]), dtype=A.dtype, device=A.device)
     lists = []
     for r, t in ((rows_a, A), (rows_g, G)):
         if r is None:
@@ -583,6 +591,19 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
         elif r.numel() < (n_list + 15) // 16 * 16:
             r = padded_row_list(r[:n_list])
         lists.append(r)
+    L = _native.lib()
+    if bf16:
+        K, N = A.shape[1], G.shape[1]
+        out = torch.empty((K, N), dtype=torch.float32, device=A.device)
+        ws_bytes = L.gcn_gemm_atg_bf16_workspace_bytes(n_list, K, N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+        with torch.cuda.device(A.device):
+            rc = L.gcn_gemm_atg_bf16(A.data_ptr(), A.stride(0), lists[0].data_ptr(), G.data_ptr(),
+                                     G.stride(0), lists[1].data_ptr(), n_list, K, N, out.data_ptr(),
+                                     out.stride(0), ws.data_ptr(), ws_bytes,
+                                     torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "gcn_gemm_atg_bf16")
+        return out.to(torch.bfloat16)
     # (no bound supplied: a reduction pass — over the LISTED rows only, the others may hold anything)
     if a_bound is None:
         src = A.detach()[:n_list] if rows_a is None else A.detach().index_select(0, rows_a[:n_list].long())
@@ -590,7 +611,6 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     if g_bound is None:
         src = G.detach()[:n_list] if rows_g is None else G.detach().index_select(0, rows_g[:n_list].long())
         g_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
-    L = _native.lib()
     out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
     ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_list)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
@@ -696,7 +716,8 @@ def _weight_grad(input, grad, a_bound=None, g_bound=None):
     bounds of both operands' maxima (the kernel's scaling needs them; two reduction passes over
     [N, 256] tensors would cost what the kernel saves), otherwise hipBLASLt with the reduction
     over the graph's vertices cut into K_SPLIT slabs."""
-    if a_bound is not None and g_bound is not None and _gemm_scheme == "h2":
+    if (a_bound is not None and g_bound is not None and _gemm_scheme == "h2") or \
+            (input.dtype == torch.bfloat16 and grad.dtype == torch.bfloat16 and input.is_cuda):
         out = weight_grad_rows(input, grad, a_bound=a_bound, g_bound=g_bound)
         if out is not None:
             return out

@@ -375,3 +375,33 @@ def test_a_bound_that_is_too_small_is_never_silent(dev):
         gemm_xw256(X, W, x_bound=good, y_absmax=torch.zeros(1, device=dev))
     finally:
         S.set_bound_check(False)
+
+
+@pytest.mark.parametrize("m,listed", [(5000, False), (70000, True), (33, True), (16, False), (1, True)])
+def test_bf16_weight_gradient_over_row_lists(dev, m, listed):
+    """gcn_gemm_atg_bf16 (config C5's weight gradients): Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] for bf16 [*, 128]
+    operands, fp32 accumulation — against an fp64 product of the same bf16-rounded values, with
+    and without row lists (gathers fused into the loads), odd list lengths, duplicates."""
+    from pygcn_amd.spmm import padded_row_list, weight_grad_rows
+    torch.manual_seed(m)
+    n = max(m, 64) * 3
+    A = torch.randn(n, 128, device=dev).bfloat16()
+    G = (torch.randn(n, 128, device=dev) * 0.01).bfloat16()
+    if listed:
+        ra = torch.randint(0, n, (m,), device=dev)
+        rg = torch.randint(0, n, (m,), device=dev)
+        got = weight_grad_rows(A, G, padded_row_list(ra), padded_row_list(rg), n_list=m)
+        ref = A[ra].double().t() @ G[rg].double()
+    else:
+        got = weight_grad_rows(A[:m], G[:m])
+        ref = A[:m].double().t() @ G[:m].double()
+    assert got is not None and got.dtype == torch.bfloat16 and tuple(got.shape) == (128, 128)
+    # fp32 accumulation of exact bf16 products, one final rounding to bf16
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2.0 ** -8 * ref.abs().max().item() + 1e-30, (err, ref.abs().max().item())
+    # deterministic: the same launch twice gives the same bits
+    again = weight_grad_rows(A, G, padded_row_list(ra), padded_row_list(rg), n_list=m) if listed else \
+        weight_grad_rows(A[:m], G[:m])
+    assert torch.equal(got, again)
+    # shapes the kernel does not carry decline (the caller falls back to a library GEMM)
+    assert weight_grad_rows(A[:, :64], G[:, :64]) is None
