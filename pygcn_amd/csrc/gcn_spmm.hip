@@ -252,11 +252,49 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
     }
 }
 
+// xor-butterfly reductions inside groups of LPR consecutive lanes (LPR a power of two).  The first
+// four steps are DPP row operations — VALU modifiers, no trip through the LDS crossbar and no
+// address registers: quad_perm [1,0,3,2] and [2,3,0,1] are the xor-1 / xor-2 exchanges; after them
+// a quad is uniform, so row_half_mirror (lane i <-> 7 - i) and row_mirror (i <-> 15 - i) act as
+// xor 4 / xor 8.  max and + are commutative, so every lane of a group ends with the same bits.
+// Wider groups finish with wave shuffles (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_max(float m)
+{
+    if (LPR >= 2) m = fmaxf(m, dpp_move<0xB1>(m));
+    if (LPR >= 4) m = fmaxf(m, dpp_move<0x4E>(m));
+    if (LPR >= 8) m = fmaxf(m, dpp_move<0x141>(m));
+    if (LPR >= 16) m = fmaxf(m, dpp_move<0x140>(m));
+#pragma unroll
+    for (int off = 16; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    return m;
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float s)
+{
+    if (LPR >= 2) s += dpp_move<0xB1>(s);
+    if (LPR >= 4) s += dpp_move<0x4E>(s);
+    if (LPR >= 8) s += dpp_move<0x141>(s);
+    if (LPR >= 16) s += dpp_move<0x140>(s);
+#pragma unroll
+    for (int off = 16; off < LPR; off <<= 1) s += __shfl_xor(s, off, kWave);
+    return s;
+}
+
 // bias add + ReLU + dropout + conversion + store of one output row segment (VEC floats per lane)
 // (a row is held by LPR consecutive lanes, VEC elements each, starting at a multiple of LPR)
-// XEPI = false compiles the log_softmax / output-row-flag code out: the plain instantiations keep
+// XEPI = 0 compiles the log_softmax / output-row-flag code out, 1 keeps log_softmax only (the last
+// layer of every forward pass: without the row-flag code the bf16 narrow instantiation keeps 6
+// waves per SIMD), 2 keeps both: the plain instantiations keep
 // the register budget they were tuned with (wide fp32: 62 VGPRs; the extras cost 8-15 more)
-template <typename T, int VEC, int LPR, bool XEPI, bool ALLOW_SKIP = true>
+template <typename T, int VEC, int LPR, int XEPI, bool ALLOW_SKIP = true>
 __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
                                           const float (&acc)[VEC], const float (&bias)[VEC])
 {
@@ -267,24 +305,22 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         if (p.relu) o[i] = fmaxf(o[i], 0.f);
     }
     if (p.drop_thresh != 0u) apply_dropout<VEC>(p, row, f, o);   // wave-uniform branch
-    if (XEPI && p.log_softmax) {   // wave-uniform; the host guarantees the whole row sits in these LPR lanes
+    if (XEPI >= 1 && p.log_softmax) {   // wave-uniform; the host guarantees the whole row sits in these LPR lanes
         const bool valid = f < p.F;
         float m = -INFINITY;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) m = valid ? fmaxf(m, o[i]) : m;
-#pragma unroll
-        for (int off = 1; off < LPR; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        m = group_max<LPR>(m);
         float se = 0.f;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) se += valid ? __expf(o[i] - m) : 0.f;   // arguments <= 0
-#pragma unroll
-        for (int off = 1; off < LPR; off <<= 1) se += __shfl_xor(se, off, kWave);
+        se = group_sum<LPR>(se);
         const float lse = m + __logf(se);   // se in [1, F]: hardware exp2 / log2, ~1e-7 absolute
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o[i] -= lse;
     }
     bool do_store = act;
-    if (XEPI && p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
+    if (XEPI >= 2 && p.cflag != nullptr) {   // wave-uniform; every lane holding a non-zero stores the same byte
         bool nz = false;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) nz |= (o[i] != 0.f);
@@ -322,7 +358,7 @@ __device__ __forceinline__ u32x4 row_load16(uint64_t base, uint32_t nbytes, uint
     return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
 }
 
-template <typename T, int VEC, int D, bool ROWS, bool FLAGS, bool XEPI>
+template <typename T, int VEC, int D, bool ROWS, bool FLAGS, int XEPI>
 __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__restrict__ colp,
                                             const float *__restrict__ valp, int ne, int lane,
                                             unsigned ld_off_bytes, float (&acc)[VEC],
@@ -441,7 +477,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     }
 }
 
-template <typename T, int VEC, typename IdxT, int D, bool FLAGS, bool XEPI>
+template <typename T, int VEC, typename IdxT, int D, bool FLAGS, int XEPI>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParams p)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -597,7 +633,7 @@ __device__ __forceinline__ void narrow_row(const KParams &p, const int32_t *__re
     }
 }
 
-template <typename T, int VEC, int LPR, typename IdxT, bool XEPI>
+template <typename T, int VEC, int LPR, typename IdxT, int XEPI>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KParams p)
 {
     constexpr int U = 4;
@@ -821,7 +857,7 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
         for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
-        store_out<T, 1, 1, true, false>(p, row, f, true, a, b);   // long rows: always stored
+        store_out<T, 1, 1, 2, false>(p, row, f, true, a, b);   // long rows: always stored
     }
 }
 
@@ -1033,15 +1069,18 @@ template <typename T, int VEC, int LPR>
 void launch_narrow(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
     const dim3 block(kWave * kWavesPerBlock);
-    const bool xepi = kp.log_softmax || kp.cflag != nullptr;   // the instantiation with the extras
+    const int xepi = kp.cflag != nullptr ? 2 : (kp.log_softmax ? 1 : 0);   // instantiation with the extras
 #define GCN_LAUNCH_NARROW(I, X) \
     hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, I, X>), grid, block, 0, s, kp)
-    if (xepi) {
-        if (is64) GCN_LAUNCH_NARROW(int64_t, true);
-        else GCN_LAUNCH_NARROW(int32_t, true);
+    if (xepi == 2) {
+        if (is64) GCN_LAUNCH_NARROW(int64_t, 2);
+        else GCN_LAUNCH_NARROW(int32_t, 2);
+    } else if (xepi == 1) {
+        if (is64) GCN_LAUNCH_NARROW(int64_t, 1);
+        else GCN_LAUNCH_NARROW(int32_t, 1);
     } else {
-        if (is64) GCN_LAUNCH_NARROW(int64_t, false);
-        else GCN_LAUNCH_NARROW(int32_t, false);
+        if (is64) GCN_LAUNCH_NARROW(int64_t, 0);
+        else GCN_LAUNCH_NARROW(int32_t, 0);
     }
 #undef GCN_LAUNCH_NARROW
 }
@@ -1070,19 +1109,19 @@ void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, I, D, FL, X>), grid, block, 0, s, kp)
     if (kp.bflag != nullptr || kp.csel != nullptr) {   // operand hint / row selection: the flag variant
         if (xepi) {
-            if (is64) GCN_LAUNCH_WIDE(int64_t, true, true);
-            else GCN_LAUNCH_WIDE(int32_t, true, true);
+            if (is64) GCN_LAUNCH_WIDE(int64_t, true, 2);
+            else GCN_LAUNCH_WIDE(int32_t, true, 2);
         } else {
-            if (is64) GCN_LAUNCH_WIDE(int64_t, true, false);
-            else GCN_LAUNCH_WIDE(int32_t, true, false);
+            if (is64) GCN_LAUNCH_WIDE(int64_t, true, 0);
+            else GCN_LAUNCH_WIDE(int32_t, true, 0);
         }
     } else {
         if (xepi) {
-            if (is64) GCN_LAUNCH_WIDE(int64_t, false, true);
-            else GCN_LAUNCH_WIDE(int32_t, false, true);
+            if (is64) GCN_LAUNCH_WIDE(int64_t, false, 2);
+            else GCN_LAUNCH_WIDE(int32_t, false, 2);
         } else {
-            if (is64) GCN_LAUNCH_WIDE(int64_t, false, false);
-            else GCN_LAUNCH_WIDE(int32_t, false, false);
+            if (is64) GCN_LAUNCH_WIDE(int64_t, false, 0);
+            else GCN_LAUNCH_WIDE(int32_t, false, 0);
         }
     }
 #undef GCN_LAUNCH_WIDE
