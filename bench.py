@@ -571,21 +571,47 @@ def main():
 
     # ---------------------------------------------------------------- untimed side measurements
     def count_host_syncs(fn):
-        """MEASURED: host synchronisations of one call of `fn` — torch's sync debug mode warns on
-        every synchronising call (`.item()`, `.tolist()`, `.cpu()`, `nonzero`, blocking copies)."""
+        """MEASURED: host synchronisations of one call of `fn`, by two detectors at once — torch's
+        sync debug mode (warns on synchronising calls; a prototype that misses some) and hooks on
+        the tensor methods that read device memory back (`.item()`, `.tolist()`, `.cpu()`,
+        `torch.nonzero`); the larger count is reported.  The detectors are checked against a
+        deliberate `.item()` first: a counter that cannot see that one reports "unmeasured"."""
         import warnings
+        hooks = []
+
+        def run(call):
+            seen = []
+            for name in ("item", "tolist", "cpu"):
+                real = getattr(torch.Tensor, name)
+                hooks.append((torch.Tensor, name, real))
+                setattr(torch.Tensor, name, (lambda r, nm: lambda t, *a, **k: (
+                    seen.append(nm) if t.is_cuda else None, r(t, *a, **k))[1])(real, name))
+            real_nz = torch.nonzero
+            hooks.append((torch, "nonzero", real_nz))
+            torch.nonzero = lambda *a, **k: (seen.append("nonzero"), real_nz(*a, **k))[1]
+            warned = 0
+            try:
+                torch.cuda.set_sync_debug_mode("warn")
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    call()
+                warned = sum("synchroniz" in str(w.message).lower() for w in caught)
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+                while hooks:
+                    obj, name, real = hooks.pop()
+                    setattr(obj, name, real)
+            return max(warned, len(seen))
         torch.cuda.synchronize()
         try:
-            torch.cuda.set_sync_debug_mode("warn")
-            with warnings.catch_warnings(record=True) as caught:
-                warnings.simplefilter("always")
-                fn()
-            return sum("synchroniz" in str(w.message).lower() for w in caught)
+            probe = torch.ones(1, device=dev)
+            if run(lambda: probe.item()) < 1:
+                return "unmeasured: the detectors did not see a deliberate .item()"
+            n_sync = run(fn)
         except Exception as ex:                  # (the counter must never cost the bench line)
             return f"unmeasured: {ex!r}"
-        finally:
-            torch.cuda.set_sync_debug_mode("default")
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return n_sync
 
     def dense_bwd_figures(l2_ms, l1_ms, n_steps):
         """The transpose product at FULL height (dense gradient): ms, GEdge/s and its roofline
@@ -736,7 +762,8 @@ def main():
                             "(set_gemm_scheme('exact'))") if dt == "f32" else "bf16 MFMA, fp32 accumulate",
             "host_syncs_per_step": syncs,
             "host_syncs_note": "MEASURED on one extra epoch of the timed kind after the timed region "
-                               "(torch.cuda.set_sync_debug_mode: every synchronising call warns); the "
+                               "(torch.cuda.set_sync_debug_mode warnings and hooks on .item() / .tolist() / "
+                               ".cpu() / nonzero, validated against a deliberate .item() first); the "
                                "dense-loss and upstream-lines epochs carry their own counts",
             "spmm_fwd_ms": round(t_fwd, 4), "spmm_bwd_ms": round(t_bwd, 4),
             "spmm_bwd_gedges": round(nnz_total / (t_bwd * 1e-3) / 1e9, 4) if bwd_ms else None,

@@ -251,6 +251,43 @@ def gcn2_loss_backward(x, adj, p, labels, idx, need_grad_x=False, relu_mask=None
     return loss, fw, grads, {"grad_h2": grad_h2, "grad_a1": ga1, "grad_h1": grad_h1, "grad_x": gx}
 
 
+def gcn2_loss_backward_f64(x, adj, p, labels, idx, relu_mask=None):
+    """The same training step (gcn2_loss_backward: models.py:23,48,68; train.py:153-157) evaluated
+    in FLOAT64 on the same float32 inputs — the arbiter when two float32 results disagree at the
+    1e-5 level: on hub columns of 10⁴–10⁵ entries the float32 CPU transpose product (the
+    reference's own arithmetic) carries ~1e-5 of rounding error itself.  scipy CSR products and
+    numpy GEMMs in float64.  Returns (loss, {"logp"}, grads)."""
+    A = sp.csr_matrix((adj.val.astype(np.float64), adj.col, adj.rowptr), shape=adj.shape)
+    At = A.T.tocsr()
+    x = np.asarray(x, np.float64)
+    W1, W2 = np.asarray(p["gc1.weight"], np.float64), np.asarray(p["gc2.weight"], np.float64)
+    h1 = A @ (x @ W1)
+    if "gc1.bias" in p:
+        h1 = h1 + np.asarray(p["gc1.bias"], np.float64)
+    mask = (h1 > 0) if relu_mask is None else relu_mask
+    a1 = np.where(mask, h1, 0.0) if relu_mask is not None else np.maximum(h1, 0)
+    h2 = A @ (a1 @ W2)
+    if "gc2.bias" in p:
+        h2 = h2 + np.asarray(p["gc2.bias"], np.float64)
+    z = h2 - h2.max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    n_tr = len(idx)
+    loss = float(-logp[idx, labels[idx]].mean())
+    g = np.zeros_like(logp)
+    np.add.at(g, (idx, labels[idx]), -1.0 / n_tr)
+    grad_h2 = g - np.exp(logp) * g.sum(1, keepdims=True)
+    gs2 = At @ grad_h2
+    grads = {"gc2.weight": a1.T @ gs2}
+    if "gc2.bias" in p:
+        grads["gc2.bias"] = grad_h2.sum(0)
+    grad_h1 = (gs2 @ W2.T) * mask
+    gs1 = At @ grad_h1
+    grads["gc1.weight"] = x.T @ gs1
+    if "gc1.bias" in p:
+        grads["gc1.bias"] = grad_h1.sum(0)
+    return loss, {"logp": logp}, grads
+
+
 class Adam:
     """torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8, weight_decay) — train.py:111-112."""
 

@@ -91,25 +91,22 @@ def test_c3_training_step_against_oracle(c3, oracle, route):
     # a convention — the oracle is given the device's, after checking the masks differ only there
     from _sampling import device_relu_mask
     mask, n_flips = device_relu_mask(oracle, model, x, g, a)
-    ref_loss, fw, grads, extra = oracle.gcn2_loss_backward(x.cpu().numpy(), a, p, labels.cpu().numpy(),
-                                                           idx.cpu().numpy(), relu_mask=mask)
+    xn, ln, idn = x.cpu().numpy(), labels.cpu().numpy(), idx.cpu().numpy()
+    ref_loss, fw, grads, _ = oracle.gcn2_loss_backward(xn, a, p, ln, idn, relu_mask=mask)
+    loss64, fw64, grads64 = oracle.gcn2_loss_backward_f64(xn, a, p, ln, idn, relu_mask=mask)
     assert abs(loss.item() - ref_loss) <= TOL * abs(ref_loss)
-    assert_normwise(out_rows.detach().cpu(), fw["logp"][idx.cpu().numpy()], TOL, route + ": log-probabilities")
+    assert_normwise(out_rows.detach().cpu(), fw["logp"][idn], TOL, route + ": log-probabilities")
+
+    def err(u, v):
+        return float(np.abs(np.asarray(u, np.float64) - np.asarray(v, np.float64)).max() / np.abs(v).max())
     for k, v in grads.items():
         mod, name = k.split(".")
-        got = getattr(getattr(model, mod), name).grad.cpu().numpy().astype(np.float64)
-        if name == "weight":
-            # (weight gradients reduce over up to 10^6 vertices: the documented 2e-5 gate)
-            assert_normwise(got, v, 2e-5, f"{route}: {k}.grad")
-        else:
-            # A bias gradient is a plain column sum of up to 10^6 signed terms that cancel to ~1 % of
-            # their absolute sum — the oracle's own float32 sum is no reference at 1e-5 of the RESULT.
-            # Reference: the oracle's per-row gradients summed in float64; gate: 1e-5 of the sum of
-            # absolute values (the backward-error scale of a float32 sum), per column.
-            rows_g = extra["grad_h1"] if mod == "gc1" else extra["grad_h2"]
-            ref = rows_g.astype(np.float64).sum(0)
-            scale = np.abs(rows_g).astype(np.float64).sum(0)
-            assert scale.max() > 5 * np.abs(ref).max()          # (the cancellation this gate is about)
-            err = np.abs(got - ref)
-            assert (err <= 1e-5 * scale).all(), f"{route}: {k}.grad: {err.max():.3e} vs {scale.max():.3e}"
-            assert_normwise(got, ref, 2e-4, f"{route}: {k}.grad (normwise, loose)")
+        got = getattr(getattr(model, mod), name).grad.cpu().numpy()
+        # Arbiter = the float64 evaluation of the same step.  The HIP result must be within the
+        # contract's 1e-5 of it for every parameter; against the float32 ORACLE the documented 2e-5
+        # holds for gradients reduced over up to 10⁶ vertices, plus whatever the oracle's own
+        # float32 transpose product lost on hub columns (the reference's CPU arithmetic sums 10⁴–10⁵
+        # terms per hub in one float32 chain; this build's chunked sums are closer to float64).
+        e_hip, e_oracle = err(got, grads64[k]), err(v, grads64[k])
+        assert e_hip <= 1e-5, f"{route}: {k}.grad vs float64: {e_hip:.3e}"
+        assert err(got, v) <= 2e-5 + e_oracle, f"{route}: {k}.grad vs oracle: {err(got, v):.3e} (oracle vs float64 {e_oracle:.3e})"
