@@ -4,10 +4,12 @@ import numpy as np
 import torch
 
 
-def sampled_rows_reference(oracle, g, B, rows, round_to=None):
+def sampled_rows_reference(oracle, g, B, rows, round_to=None, f64=False):
     """oracle.spmm_csr on the sub-problem made of `rows` of CSRGraph `g` and the rows of B they
     reference.  `round_to`: optional torch dtype the operand is stored in (bf16): the reference then
-    works on the rounded values in fp32."""
+    works on the rounded values in fp32.  `f64`: accumulate in float64 (oracle.spmm_csr_f64acc) —
+    the arbiter for rows of 10⁴–10⁵ entries, where a single float32 chain (the CPU reference's own
+    arithmetic) carries ~1e-5 of rounding error itself."""
     dev = g.device
     rows = rows.to(dev).long()
     starts, ends = g.rowptr[rows].long(), g.rowptr[rows + 1].long()
@@ -21,8 +23,9 @@ def sampled_rows_reference(oracle, g, B, rows, round_to=None):
     Bs = B[ucols]
     if round_to is not None:
         Bs = Bs.to(round_to)
-    return oracle.spmm_csr(rp.cpu().numpy(), inv.cpu().numpy().astype(np.int32), vals.cpu().numpy(),
-                           Bs.float().cpu().numpy())
+    fn = oracle.spmm_csr_f64acc if f64 else oracle.spmm_csr
+    return fn(rp.cpu().numpy(), inv.cpu().numpy().astype(np.int32), vals.cpu().numpy(),
+              Bs.float().cpu().numpy())
 
 
 def heavy_and_random_rows(g, n_heavy, n_random, gen):

@@ -97,8 +97,17 @@ def test_sampled_rows_of_the_transpose_product_against_oracle(c4, oracle):
     out = spmm_csr(gt, G)
     rows, heaviest = heavy_and_random_rows(gt, 40, 3000, gen)
     assert heaviest > 20000
-    assert_normwise(out[rows].cpu(), sampled_rows_reference(oracle, gt, G, rows), 1e-5,
-                    "C4 transpose product: sampled rows incl. the heaviest columns")
+    # Rows of Âᵀ are not normalized: a hub column sums 10⁴–10⁵ terms to magnitudes ~10², and the
+    # float32 CPU chain loses ~1e-5 there by itself.  Arbiter: float64 accumulation of the same
+    # float32 products; the HIP result must be within the contract's 1e-5 of it, and within 2e-5 +
+    # (the float32 oracle's own distance from float64) of the float32 oracle.
+    got = out[rows].cpu().numpy()
+    ref64 = sampled_rows_reference(oracle, gt, G, rows, f64=True)
+    ref32 = sampled_rows_reference(oracle, gt, G, rows)
+    assert_normwise(got, ref64, 1e-5, "C4 transpose product vs float64: sampled rows incl. the heaviest columns")
+    scale = np.abs(ref64).max()
+    e_oracle = np.abs(ref32.astype(np.float64) - ref64).max() / scale
+    assert np.abs(got.astype(np.float64) - ref32).max() / scale <= 2e-5 + e_oracle
 
 
 def test_transpose_block_equals_the_full_transpose_product(c4):
