@@ -89,6 +89,10 @@ def parse():
                     help="multi-GPU exchange step: rows a rank references only, or full all-gather")
     ap.add_argument("--no-overlap", action="store_true",
                     help="multi-GPU: exchange, then one product (no source-block pipelining)")
+    ap.add_argument("--compress-hidden", action="store_true",
+                    help="multi-GPU A/B switch: layer 2's input rows (>= 75 %% zeros after ReLU + "
+                         "dropout) travel as bitmask + non-zero values and meet W2 on arrival, instead "
+                         "of dense rows of h1 x W2 (pygcn_amd/sharded.py: product_hidden)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # launcher test
     ap.add_argument("--rehearsal", action="store_true",
@@ -385,7 +389,8 @@ def main():
         from pygcn_amd.sharded import ShardedGraph, ShardedGCN
         torch.cuda.reset_peak_memory_stats(dev)
         adj = ShardedGraph.from_rmat(n, e, rank, world, dev, seed=42, perm_seed=43,
-                                     exchange=args.exchange, overlap=not args.no_overlap, **kw)
+                                     exchange=args.exchange, overlap=not args.no_overlap,
+                                     compress_hidden=args.compress_hidden, **kw)
         torch.cuda.synchronize()
         t_gen = time.perf_counter() - t0
         peak_setup = torch.cuda.max_memory_allocated(dev)
@@ -809,6 +814,11 @@ def main():
             line["exchange_bytes_received_per_rank_max"] = {"fwd_dense": recv_max[0],
                                                             "bwd_sparse": recv_max[1]}
             line["setup_peak_bytes_per_rank_max"] = peak_setup
+            line["setup_s_rank0"] = round(t_gen, 2)
+            line["setup_stats_rank0"] = adj.setup_stats
+            line["hidden_exchange"] = ("compressed: bitmask + non-zero values, W2 applied on arrival "
+                                       "(--compress-hidden)") if adj.compress_hidden else \
+                "dense rows of h1 x W2 (default; --compress-hidden is the A/B switch)"
             line["exchange_exposed_wait_ms_rank0"] = round(float(np.mean(wait_ms)), 4) if wait_ms else None
             line["exchange_exposed_wait_note"] = ("time the compute stream waits for the halo rows "
                                                   "AFTER the own-rows product has run under the "

@@ -69,7 +69,7 @@ def nll_loss(log_probs, target):
     rowgrad.RowSelectable), its gradient travels in STRUCTURAL form (NLLGrad: the label vector and
     one coefficient) — the only consumer is then the model's autograd node, which declared it can
     take it; any other tensor gets the ordinary dense gradient."""
-    from .rowgrad import RowSelectable
+    from pygcn_amd.rowgrad import RowSelectable
     structural = (isinstance(log_probs, RowSelectable) and log_probs.dim() == 2 and log_probs.is_cuda
                   and log_probs.requires_grad and target.dtype == torch.int64
                   and target.device == log_probs.device)

@@ -22,8 +22,8 @@ if not __package__:   # imported flat, the reference's convention (`from layers 
 from pygcn_amd.graph import CSRGraph, _require_cuda, as_graph  # noqa: E402
 from pygcn_amd.spmm import (DenseMMFunction, GraphConvFunction, SpMMFunction,  # noqa: E402
                             dropout_seed_for, log_softmax_fusable)
-from pygcn_amd.sharded import (ShardedGraph, ShardedInputLayerFunction,  # noqa: E402
-                               ShardedSpMMFunction)
+from pygcn_amd.sharded import (ShardedGraph, ShardedHiddenLayerFunction,  # noqa: E402
+                               ShardedInputLayerFunction, ShardedSpMMFunction)
 
 
 class GraphConvolution(Module):
@@ -69,6 +69,13 @@ class GraphConvolution(Module):
                 _require_cuda(self.weight, "GraphConvolution.weight (call model.cuda())")
                 return GraphConvFunction.apply(input, self.weight, self.bias, as_graph(adj), False,
                                                0.0, 0, True)
+            if (isinstance(adj, ShardedGraph) and input.dim() == 2 and adj.compress_hidden
+                    and not adj.is_constant_input(input) and input.shape[1] % 32 == 0):
+                # hidden activation, compressed exchange (ShardedGraph(compress_hidden=True))
+                fuse = adj._hinted_product and input.is_cuda and log_softmax_fusable(self.out_features, input.dtype)
+                out = ShardedHiddenLayerFunction.apply(adj, input, self.weight, self.bias, False, 0.0, 0,
+                                                       fuse, True)
+                return out if fuse else torch.nn.functional.log_softmax(out, dim=-1)
             if (isinstance(adj, ShardedGraph) and input.dim() == 2 and input.is_cuda and adj._hinted_product
                     and not adj.is_constant_input(input)
                     and log_softmax_fusable(self.out_features, input.dtype)):
@@ -76,6 +83,12 @@ class GraphConvolution(Module):
                 # completes the rank's rows (after the halo rows have arrived)
                 return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
                                                  self.bias, False, 0.0, 0, True)
+            if isinstance(adj, ShardedGraph) and input.dim() == 2 and not adj.is_constant_input(input):
+                # (a class count the fused log_softmax does not take: still the model's LAST layer —
+                #  the declared loss rows bound its gradient's rows)
+                out = ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
+                                                self.bias, False, 0.0, 0, False, True)
+                return torch.nn.functional.log_softmax(out, dim=-1)
             return torch.nn.functional.log_softmax(self.forward(input, adj), dim=-1)
         if input.dim() == 3:
             out = self._forward_batched(input, adj, relu)
@@ -86,6 +99,8 @@ class GraphConvolution(Module):
             if adj.is_constant_input(input):     # feature block: halo rows held, no exchange
                 return ShardedInputLayerFunction.apply(adj, input, adj.constant_halo(input),
                                                        self.weight, self.bias, relu, dropout, seed)
+            if adj.compress_hidden and input.dim() == 2 and input.shape[1] % 32 == 0:
+                return ShardedHiddenLayerFunction.apply(adj, input, self.weight, self.bias, relu, dropout, seed)
             return ShardedSpMMFunction.apply(adj, DenseMMFunction.apply(input, self.weight),
                                              self.bias, relu, dropout, seed)
         _require_cuda(input, "input")

@@ -182,6 +182,46 @@ def transpose_block_by_exchange(a_block, bounds, rank, world, group=None):
     return rp.to(rowptr.dtype), src, vals
 
 
+def pack_bits(mask):
+    """bool [m, F] (F a multiple of 32) -> int32 [m, F / 32]: bit j of word w = mask[:, 32w + j]."""
+    m, F = mask.shape
+    w = (mask.view(m, F // 32, 32).to(torch.int64) << torch.arange(32, device=mask.device)).sum(-1)
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+def unpack_bits(bits, F):
+    """Inverse of pack_bits: int32 [m, F / 32] -> bool [m, F]."""
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32)
+    return ((bits[:, :, None] >> sh) & 1).bool().reshape(bits.shape[0], F)
+
+
+def redistribute_rows(key, n, bounds, rank, world, group=None):
+    """Sorted global entry keys (row·n + col) held by the ranks for ANY ascending contiguous row
+    ranges -> the keys of this rank's final block [bounds[rank], bounds[rank+1]), by one grouped
+    point-to-point round: every rank cuts its sorted keys at the final boundaries and sends each
+    range to its owner; ranges arrive in source order, which is key order (the held ranges
+    ascend with the rank).  Returns (keys of the final block, entries received from others)."""
+    dev = key.device
+    b = torch.tensor(bounds, dtype=torch.int64, device=dev)
+    cut = torch.searchsorted(key, b * n)
+    mine = (cut[1:] - cut[:-1]).contiguous()
+    M = torch.empty(world * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(M, mine, group=group)
+    M = M.view(world, world).tolist()                      # M[s][r]: s holds for r
+    cut = cut.tolist()
+    got = {s: torch.empty(M[s][rank], dtype=torch.int64, device=dev) for s in range(world) if s != rank}
+    sends, recvs = [], []
+    for k in range(1, world):
+        p = (rank + k) % world
+        sends.append((key[cut[p]:cut[p + 1]], p))
+    for k in range(1, world):
+        q = (rank - k) % world
+        recvs.append((got[q], q))
+    _p2p_round(sends, recvs, group)
+    out = torch.cat([key[cut[rank]:cut[rank + 1]] if s == rank else got[s] for s in range(world)])
+    return out, sum(int(t.numel()) for t in got.values())
+
+
 class HaloExchange:
     """Which rows of every other rank's block this rank's CSR block references, and the send
     lists the other ranks asked of this rank.  Built once per (block, process group)."""
@@ -215,6 +255,8 @@ class HaloExchange:
         self.n_halo = sum(recv_counts)
         self.n_send = sum(self.send_counts)
         self.last_recv_bytes = 0
+        self._static = {}            # static_key -> who sends which rows (exchange_sparse)
+        self.n_count_exchanges = 0   # count all-gathers run by exchange_sparse (diagnostic)
         # start of each peer's segment in send_idx / in the packed send buffer (peers in rank order)
         self.send_off, acc = [], 0
         for s in range(world):
@@ -274,30 +316,96 @@ class HaloExchange:
         self.exchange_end(pending)
         return halo
 
-    def exchange_sparse(self, local, row_nonzero):
+    def exchange_compressed_begin(self, local):
+        """Post the exchange of the requested rows of `local` [n_local, F] (F a multiple of 32) in
+        COMPRESSED form — per row a bitmask of its non-zero elements (F / 8 bytes) and the non-zero
+        values only — for operands that are mostly zeros (a hidden activation after ReLU and
+        dropout keeps <= 25 % of its elements: ≈ 3.5 x fewer bytes than dense rows).  The message
+        lengths depend on the data: one W x W all-gather of value counts and its host read precede
+        the transfers.  Returns the state for exchange_compressed_end()."""
+        F, dev, W = local.shape[1], local.device, self.world
+        if W == 1:
+            return None
+        rows = local.index_select(0, self.send_idx)                       # [n_send, F]
+        mask = rows != 0
+        bits = pack_bits(mask)                                            # int32 [n_send, F / 32]
+        vals = rows[mask]                                                 # non-zero values, row-major
+        per_row = mask.sum(1)
+        csum = torch.zeros(self.n_send + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(per_row, 0, out=csum[1:])
+        off = torch.tensor(self.send_off + [self.n_send], dtype=torch.int64, device=dev)
+        vcut = csum[off]                                                  # value offsets per peer
+        mine = (vcut[1:] - vcut[:-1]).contiguous()
+        M = torch.empty(W * W, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(M, mine, group=self.group)
+        M = M.view(W, W).tolist()                                         # M[s][r]: values s sends r
+        vcut = vcut.tolist()
+        bits_halo = torch.empty((self.n_halo, F // 32), dtype=torch.int32, device=dev)
+        sends, recvs, parts = [], [], {}
+        for k in range(1, W):
+            p = (self.rank + k) % W
+            a, b = self.send_off[p], self.send_off[p] + self.send_counts[p]
+            sends += [(bits[a:b], p), (vals[vcut[p]:vcut[p + 1]], p)]
+        for k in range(1, W):
+            r = (self.rank - k) % W
+            o = self.halo_off[r]
+            parts[r] = torch.empty(M[r][self.rank], dtype=local.dtype, device=dev)
+            recvs += [(bits_halo[o:o + self.recv_counts[r]], r), (parts[r], r)]
+        pending = _p2p_begin(sends, recvs, self.group)
+        self.last_recv_bytes = self.n_halo * (F // 8) + sum(int(t.numel()) for t in parts.values()) * local.element_size()
+        return pending, (bits, vals), bits_halo, parts, F, local.dtype      # (send buffers kept alive)
+
+    def exchange_compressed_end(self, state, like):
+        """Wait for the compressed exchange and expand it: -> dense halo rows [n_halo, F]."""
+        if state is None:
+            return like.new_zeros((self.n_halo, like.shape[1]))
+        pending, _keep, bits_halo, parts, F, dtype = state
+        _p2p_end(pending)
+        halo = torch.zeros((self.n_halo, F), dtype=dtype, device=bits_halo.device)
+        if self.n_halo:
+            vals = torch.cat([parts[r] for r in range(self.world) if r != self.rank])   # halo (owner) order
+            halo[unpack_bits(bits_halo, F)] = vals
+        return halo
+
+    def exchange_sparse(self, local, row_nonzero, static_key=None):
         """The same exchange for a ROW-SPARSE operand (gradients of a loss on few labelled vertices:
         most requested rows are entirely zero).  `row_nonzero(idx)` -> bool tensor: is row idx[i] of
         `local` non-zero.  Only the non-zero requested rows travel, each peer's message preceded by
         the positions of those rows in its request list; the receiver scatters them into a zeroed
         halo buffer.  One tiny all-gather tells every rank how many rows each peer will send (the
-        only host synchronisation); every rank must call this together, like exchange()."""
+        only host synchronisation); every rank must call this together, like exchange().
+
+        `static_key` (any hashable; the SAME on every rank): the caller promises that `row_nonzero`
+        describes a STRUCTURAL row set that does not change between calls with this key (the loss
+        rows — ShardedGCN.declare_loss_rows).  Who sends how many rows to whom is then worked out on
+        the first call and kept: later calls run no count exchange and no host synchronisation.
+        (Rows of the set that happen to be zero still travel: the set is structural, not data.)"""
         F, dev, W = local.shape[1], local.device, self.world
         halo = torch.zeros((self.n_halo, F), dtype=local.dtype, device=dev)
         self.last_halo_nonzero = torch.zeros(self.n_halo, dtype=torch.bool, device=dev)
         self.last_recv_bytes = 0
         if W == 1:
             return halo
-        keep = row_nonzero(self.send_idx)                                   # [n_send] bool
-        nz = torch.nonzero(keep).squeeze(1)                                 # sorted send positions
-        off = torch.tensor(self.send_off + [self.n_send], dtype=torch.int64, device=dev)
-        cut = torch.searchsorted(nz, off)                                   # split by peer
-        mine = (cut[1:] - cut[:-1]).contiguous()                            # rows I send to each peer
-        M = torch.empty(W * W, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(M, mine, group=self.group)
-        M = M.view(W, W).tolist()                                           # M[s][r]: s sends r
-        cut = cut.tolist()
-        rows = local.index_select(0, self.send_idx.index_select(0, nz))     # packed non-zero rows
-        pos = (nz - off[:-1].repeat_interleave(mine)).to(torch.int32)       # position in the request
+        cached = self._static.get(static_key) if static_key is not None else None
+        if cached is None:
+            keep = row_nonzero(self.send_idx)                                   # [n_send] bool
+            nz = torch.nonzero(keep).squeeze(1)                                 # sorted send positions
+            off = torch.tensor(self.send_off + [self.n_send], dtype=torch.int64, device=dev)
+            cut = torch.searchsorted(nz, off)                                   # split by peer
+            mine = (cut[1:] - cut[:-1]).contiguous()                            # rows I send to each peer
+            M = torch.empty(W * W, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(M, mine, group=self.group)
+            M = M.view(W, W).tolist()                                           # M[s][r]: s sends r
+            cut = cut.tolist()
+            src_rows = self.send_idx.index_select(0, nz)                        # local rows to pack
+            pos = (nz - off[:-1].repeat_interleave(mine)).to(torch.int32)       # position in the request
+            n_nz = int(nz.numel())
+            if static_key is not None:
+                self._static[static_key] = (M, cut, src_rows, pos, n_nz)
+            self.n_count_exchanges += 1
+        else:
+            M, cut, src_rows, pos, n_nz = cached
+        rows = local.index_select(0, src_rows)                                  # packed rows
         sends, recvs, landed = [], [], []
         for k in range(1, W):
             p = (self.rank + k) % W
@@ -316,7 +424,7 @@ class HaloExchange:
                 dst = rp.to(torch.int64) + self.halo_off[r]
                 halo.index_copy_(0, dst, rr)
                 self.last_halo_nonzero[dst] = True
-        self.last_sparse_rows = (int(nz.numel()), self.n_send)              # sent / dense (stats)
+        self.last_sparse_rows = (n_nz, self.n_send)                         # sent / dense (stats)
         self.last_recv_bytes = sum(int(rp.numel()) for _, rp, _ in landed) * (F * local.element_size() + 4)
         return halo
 
@@ -327,7 +435,7 @@ class ShardedGraph:
 
     def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
                  graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias,
-                 sparse_grad_exchange=True, overlap=True, **plan_kw):
+                 sparse_grad_exchange=True, overlap=True, compress_hidden=False, **plan_kw):
         if exchange not in ("halo", "allgather"):
             raise RuntimeError("exchange must be 'halo' or 'allgather'")
         # dense halo exchanges are pipelined by source block (own rows | halo rows), see product()
@@ -337,6 +445,10 @@ class ShardedGraph:
         # backward exchanges send only the non-zero gradient rows (halo mode; must be set
         # identically on every rank: it selects the message protocol)
         self.sparse_grad_exchange = bool(sparse_grad_exchange) and exchange == "halo"
+        # hidden-layer inputs (>= 75 % zeros after ReLU + dropout) travel as bitmask + non-zero
+        # values and are multiplied by the weight on arrival (product_hidden); must be set
+        # identically on every rank: it selects the message protocol
+        self.compress_hidden = bool(compress_hidden) and exchange == "halo"
         self._hinted_product = spmm_fn is spmm_csr     # test stand-ins take no operand hint
         self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
         self.exchange_mode = exchange
@@ -365,6 +477,9 @@ class ShardedGraph:
         self._const_ref = None      # weakref to the registered constant input (feature matrix)
         self._const_halo = None     # (version, halo rows) of that tensor
         self.n_const_exchanges = 0
+        self.setup_stats = None     # filled by the shard-local constructors (from_rmat)
+        self.static_grad_rows = None    # see declare_grad_rows
+        self._grad_rows_version = 0
 
     @classmethod
     def from_global_csr(cls, rowptr, col, val, n, rank, world, device=None, group=None, **kw):
@@ -392,24 +507,32 @@ class ShardedGraph:
     @classmethod
     def from_rmat(cls, n, n_edges, rank, world, device, seed=42, perm_seed=43, group=None, **kw):
         """The synthetic graph of configs C3–C5 (`utils.rmat_graph(n, n_edges, seed, perm_seed)`:
-        the same matrix, entry for entry) built shard-locally: (1) every rank generates the rows of
-        a provisional uniform block and counts their stored entries, (2) the counts are
-        all-gathered (n integers) and give the nnz-balanced bounds, (3) every rank generates its
-        final row block, (4) the Âᵀ blocks are assembled by the triplet exchange.  The edge stream
-        is replayed, never stored: O(chunk) + O(nnz / P) memory per rank."""
-        from .utils import rmat_row_block
+        the same matrix, entry for entry) built shard-locally in ONE pass over the edge stream:
+        (1) every rank replays the stream once and keeps the (deduplicated) entries of a
+        provisional uniform row block, (2) the per-row counts are all-gathered (n integers) and
+        give the nnz-balanced bounds, (3) the ranks hand the rows that changed owner straight to
+        their final owners (`redistribute_rows`: one grouped point-to-point round of sorted key
+        ranges — a boundary moves by a fraction of a block, so little travels), (4) the Âᵀ blocks
+        are assembled by the triplet exchange.  The edge stream is replayed, never stored:
+        O(chunk) + O(nnz / P) memory per rank.  `setup_stats` records what moved."""
+        from .utils import csr_from_keys, rmat_block_keys
         step = -(-n // world)
         p0, p1 = min(rank * step, n), min((rank + 1) * step, n)
+        key = rmat_block_keys(n, n_edges, p0, p1, seed, perm_seed, device)
         deg = torch.zeros(step, dtype=torch.int64, device=device)
-        deg[:p1 - p0] = rmat_row_block(n, n_edges, p0, p1, seed, perm_seed, device, counts_only=True)
+        deg[:p1 - p0] = torch.bincount(key // n - p0, minlength=p1 - p0)
         allc = torch.empty(world * step, dtype=torch.int64, device=device)
         dist.all_gather_into_tensor(allc, deg, group=group)
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
         torch.cumsum(allc[:n], 0, out=rowptr[1:])      # blocks are contiguous: padding only at the end
         bounds = partition_rows(rowptr, world)
         del rowptr, allc, deg
-        a_block = rmat_row_block(n, n_edges, bounds[rank], bounds[rank + 1], seed, perm_seed, device)
-        return cls.from_row_block(bounds, rank, world, a_block, group=group, **kw)
+        key, moved = redistribute_rows(key, n, bounds, rank, world, group)
+        a_block = csr_from_keys(key, n, bounds[rank], bounds[rank + 1])
+        del key
+        sg = cls.from_row_block(bounds, rank, world, a_block, group=group, **kw)
+        sg.setup_stats = {"edge_stream_passes": 1, "entries_received_in_rebalance": moved}
+        return sg
 
     # ---------------------------------------------------------------- exchange step
     def all_gather_rows(self, local):
@@ -466,6 +589,19 @@ class ShardedGraph:
             self._split[transpose] = (a_own, csr(rows, cols[perm], vals[perm], h.n_halo + n_loc))
         return self._split[transpose]
 
+    # ---------------------------------------------------------------- static loss rows
+    def declare_grad_rows(self, mask_local):
+        """`mask_local` (bool [n_local]) — the rows of this rank's block on which the gradient
+        entering the LAST layer can be non-zero (the loss rows), or None to withdraw.  With it, the
+        row-sparse backward exchange of that layer is STATIC: the count exchange and its host
+        synchronisation happen once, not per step.  Must be called on every rank alike (the
+        protocol — count exchange or not — follows from it)."""
+        if mask_local is not None:
+            if mask_local.dtype != torch.bool or mask_local.numel() != self.n_local:
+                raise RuntimeError("declare_grad_rows: bool mask over this rank's rows expected")
+            self._grad_rows_version += 1
+        self.static_grad_rows = mask_local
+
     # ---------------------------------------------------------------- constant input
     def register_constant_input(self, t):
         """Declare `t` [n_local, F] (this rank's rows of the input feature matrix) constant across
@@ -507,7 +643,7 @@ class ShardedGraph:
             self.timing.append((tag, ev[0], ev[1]))
 
     def product(self, local, transpose=False, bias=None, relu=False, dropout_p=0.0, seed=0,
-                row_nonzero=None, own_flags=None, log_softmax=False):
+                row_nonzero=None, own_flags=None, log_softmax=False, static_key=None):
         """Exchange + local product.  `row_nonzero` (callable idx -> bool, see
         HaloExchange.exchange_sparse) marks `local` as row-sparse: only its non-zero rows travel;
         with `own_flags` (bool [n_local], the same information for all own rows) the local product
@@ -539,7 +675,7 @@ class ShardedGraph:
                 self.last_recv_bytes[which] = h.last_recv_bytes
                 self._toc(ev, which)
                 return out
-            halo = h.exchange_sparse(local, row_nonzero) if row_nonzero is not None else \
+            halo = h.exchange_sparse(local, row_nonzero, static_key) if row_nonzero is not None else \
                 h.exchange(local)
             self.last_recv_bytes[which] = h.last_recv_bytes
             if row_nonzero is not None and own_flags is not None and self._hinted_product:
@@ -556,6 +692,35 @@ class ShardedGraph:
         self._toc(ev, which)
         return out
 
+    def product_hidden(self, h_local, weight, bias=None, relu=False, dropout_p=0.0, seed=0,
+                       log_softmax=False, h_bound=None):
+        """out_r = epilogue(Â_r · ([h_r ; h_halo] · W) + b) for a HIDDEN-layer input h (mostly zeros
+        after ReLU + dropout): the halo rows of h travel compressed (bitmask + non-zero values,
+        HaloExchange.exchange_compressed_begin), are expanded on arrival and multiplied by W here
+        — the GEMM of the halo rows is recomputed locally instead of its dense result being sent.
+        Pipelined like product(): the own-rows GEMM and the product over the entries that
+        reference own rows run while the compressed rows are in flight.  Same result as
+        product(h·W) up to fp32 summation order."""
+        from .spmm import _dense_forward as gemm
+        ev = self._tic(h_local)
+        h = self.halo
+        kw = {"dropout_p": dropout_p, "seed": seed, "row_base": self.r0} if dropout_p > 0.0 else {}
+        if log_softmax:
+            kw["log_softmax"] = True
+        a_own, a_halo = self.split_block(False)
+        state = h.exchange_compressed_begin(h_local.detach())
+        sup_own = gemm(h_local, weight, h_bound)
+        part = self._spmm(a_own, sup_own, tag="fwd_local")            # overlaps the transfers
+        ev_w = self._tic(h_local)
+        h_halo = h.exchange_compressed_end(state, h_local)
+        self._toc(ev_w, "fwd_wait")
+        sup_halo = gemm(h_halo, weight, h_bound) if h_halo.shape[0] else \
+            h_halo.new_empty((0, weight.shape[1]))
+        out = self._spmm(a_halo, sup_halo, bias=bias, relu=relu, tag="fwd_local", B2=part, **kw)
+        self.last_recv_bytes["fwd"] = h.last_recv_bytes
+        self._toc(ev, "fwd")
+        return out
+
     def exchange_rows(self):
         """(rows received per forward product, rows an all-gather would have received)."""
         recv = self.halo.n_halo if self.halo is not None else self.n_global - self.n_local
@@ -570,12 +735,14 @@ class ShardedSpMMFunction(torch.autograd.Function):
     """out_r = Â_r · allgather(support);  grad_support_r = (Âᵀ)_r · allgather(grad_out)."""
 
     @staticmethod
-    def forward(ctx, sg, support_local, bias, relu=False, dropout_p=0.0, seed=0, log_softmax=False):
+    def forward(ctx, sg, support_local, bias, relu=False, dropout_p=0.0, seed=0, log_softmax=False,
+                last_layer=False):
         if dropout_p > 0.0 and not relu:
             raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
         if log_softmax and relu:
             raise RuntimeError("log_softmax cannot be combined with the fused ReLU / dropout")
         ctx.sg = sg
+        ctx.last_layer = bool(last_layer or log_softmax)
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
         ctx.log_softmax = bool(log_softmax)
@@ -597,17 +764,79 @@ class ShardedSpMMFunction(torch.autograd.Function):
                                             **({"log_softmax": True} if ctx.log_softmax else {}))
         if ctx.needs_input_grad[1]:
             grad_out = grad_out.contiguous()
-            row_nonzero = flags = None
+            row_nonzero = flags = static_key = None
             if sg.sparse_grad_exchange:
-                # gradients of a loss on few labelled vertices: most rows are zero and need not
-                # travel.  The fused backward pass already produced the row bitmap; without it
-                # (shapes outside that kernel) the flags are computed here
-                flags = unpack_row_flags(hint[0], grad_out.shape[0]) if hint is not None else \
-                    (grad_out != 0).any(1)
+                if ctx.last_layer and sg.static_grad_rows is not None:
+                    # the loss rows were declared (declare_grad_rows): a structural row set — the
+                    # count exchange ran once, this step synchronises with nobody
+                    flags = sg.static_grad_rows
+                    static_key = ("loss rows", sg._grad_rows_version)
+                else:
+                    # gradients of a loss on few labelled vertices: most rows are zero and need not
+                    # travel.  The fused backward pass already produced the row bitmap; without it
+                    # (shapes outside that kernel) the flags are computed here
+                    flags = unpack_row_flags(hint[0], grad_out.shape[0]) if hint is not None else \
+                        (grad_out != 0).any(1)
                 row_nonzero = lambda idx: flags[idx]
             grad_support = sg.product(grad_out, transpose=True, row_nonzero=row_nonzero,
-                                      own_flags=flags if row_nonzero is not None else None)
-        return None, grad_support, grad_bias, None, None, None, None
+                                      own_flags=flags if row_nonzero is not None else None,
+                                      static_key=static_key)
+        return None, grad_support, grad_bias, None, None, None, None, None
+
+
+class ShardedHiddenLayerFunction(torch.autograd.Function):
+    """The layer on a sharded graph with a HIDDEN activation as its input and the compressed
+    exchange switched on (ShardedGraph(compress_hidden=True)):
+
+        forward   out_r = epilogue(Â_r · ([h_r ; h_halo] · W) + b)      (product_hidden: rows of h travel
+                                                                       as bitmask + values, the halo
+                                                                       rows' GEMM runs on arrival)
+        backward  as the uncompressed layer: grad_support_r = (Âᵀ)_r · exchange(grad_pre) (row-sparse
+                  exchange), grad_W = h_rᵀ · grad_support_r, grad_h = grad_support_r · Wᵀ — the
+                  recomputed halo GEMM is a replica of its owner's rows and owns no gradient."""
+
+    @staticmethod
+    def forward(ctx, sg, h_local, weight, bias, relu=False, dropout_p=0.0, seed=0, log_softmax=False,
+                last_layer=False):
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("fused dropout needs the fused ReLU (out > 0 encodes the mask)")
+        ctx.sg = sg
+        ctx.has_bias = bias is not None
+        ctx.relu, ctx.log_softmax = bool(relu), bool(log_softmax)
+        ctx.last_layer = bool(last_layer or log_softmax)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        from .spmm import known_absmax
+        bound = known_absmax(h_local) if (h_local.is_cuda and h_local.dtype == torch.float32) else None
+        out = sg.product_hidden(h_local, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
+                                log_softmax=log_softmax, h_bound=bound)
+        ctx.save_for_backward(h_local, weight, *([out] if (relu or log_softmax) else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .spmm import _dense_grads
+        sg = ctx.sg
+        h_local, weight = ctx.saved_tensors[:2]
+        out = ctx.saved_tensors[2] if (ctx.relu or ctx.log_softmax) else None
+        need_h, need_w, need_b = ctx.needs_input_grad[1:4]
+        grad_pre, grad_bias, hint = sg._bwd(grad_out, out, ctx.relu, ctx.scale, ctx.has_bias and need_b,
+                                            **({"log_softmax": True} if ctx.log_softmax else {}))
+        grad_h = grad_w = None
+        if need_h or need_w:
+            grad_pre = grad_pre.contiguous()
+            row_nonzero = flags = static_key = None
+            if sg.sparse_grad_exchange:
+                if ctx.last_layer and sg.static_grad_rows is not None:
+                    flags, static_key = sg.static_grad_rows, ("loss rows", sg._grad_rows_version)
+                else:
+                    flags = unpack_row_flags(hint[0], grad_pre.shape[0]) if hint is not None else \
+                        (grad_pre != 0).any(1)
+                row_nonzero = lambda idx: flags[idx]
+            grad_support = sg.product(grad_pre, transpose=True, row_nonzero=row_nonzero,
+                                      own_flags=flags if row_nonzero is not None else None,
+                                      static_key=static_key)
+            grad_h, grad_w = _dense_grads(h_local, weight, grad_support, need_h, need_w)
+        return None, grad_h, grad_w, grad_bias, None, None, None, None, None
 
 
 class ShardedInputLayerFunction(torch.autograd.Function):
@@ -749,6 +978,17 @@ class ShardedGCN(torch.nn.Module):
         return sf.ShardedGCN2RowsFunction.apply(sg, rs, x_local, sg.constant_halo(x_local),
                                                 m.gc1.weight, m.gc1.bias, m.gc2.weight, m.gc2.bias,
                                                 float(p), seed)
+
+    def declare_loss_rows(self, idx_local):
+        """Layer-by-layer path: tell the sharded graph which local rows the loss reads (None to
+        withdraw), so the row-sparse gradient exchange of the last layer becomes static
+        (ShardedGraph.declare_grad_rows).  Every rank must call it alike."""
+        if idx_local is None:
+            self.sg.declare_grad_rows(None)
+            return
+        mask = torch.zeros(self.sg.n_local, dtype=torch.bool, device=idx_local.device)
+        mask[idx_local.long()] = True
+        self.sg.declare_grad_rows(mask)
 
     def prepare_rows(self, rows_local):
         """COLLECTIVE: the static backward structure for the loss rows of every rank (local row

@@ -126,7 +126,12 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
         if h1 is None:
             raise RuntimeError("sharded one-node path: the layer GEMM declined the operands")
         ctx.h_bound = h_bound
-        logp = sg.product(_dense_forward(h1, w2, h_bound), bias=b2, log_softmax=True)
+        if sg.compress_hidden and h1.shape[1] % 32 == 0:
+            # h1 is >= 75 % zeros (ReLU + dropout): its halo rows travel as bitmask + values and meet
+            # W2 on arrival (ShardedGraph.product_hidden) instead of dense rows of h1·W2 travelling
+            logp = sg.product_hidden(h1, w2, bias=b2, log_softmax=True, h_bound=h_bound)
+        else:
+            logp = sg.product(_dense_forward(h1, w2, h_bound), bias=b2, log_softmax=True)
         out_rows = logp.index_select(0, rs.rows_user)
         ctx.save_for_backward(z, w1, w2, h1, out_rows)
         ctx.has_bias = (b1 is not None, b2 is not None)

@@ -143,12 +143,11 @@ def vertex_permutation(n, perm_seed, device):
     return torch.randperm(n, generator=gen, device=device)
 
 
-def rmat_row_block(n, n_edges, r0, r1, seed=42, perm_seed=43, device="cpu", counts_only=False):
-    """Rows [r0, r1) of the SAME normalized adjacency `rmat_graph(n, n_edges, seed, perm_seed)`
-    builds, generated without ever holding the other rows: the edge stream is replayed chunk by
-    chunk and only pairs whose (relabelled) source lies in the block are kept.  Returns
-    (rowptr rebased to 0, col global ids int32, val fp32); with `counts_only` just the stored
-    entries per row (int64 [r1 - r0]) — all a partitioner needs."""
+def rmat_block_keys(n, n_edges, r0, r1, seed=42, perm_seed=43, device="cpu"):
+    """Stored entries of rows [r0, r1) of the normalized adjacency `rmat_graph(n, n_edges, seed,
+    perm_seed)` as sorted unique GLOBAL keys row·n + col (self-loops included): the edge stream is
+    replayed chunk by chunk and only pairs whose (relabelled) source lies in the block are kept —
+    O(chunk) + O(block) memory."""
     device = torch.device(device)
     perm = vertex_permutation(n, perm_seed, device) if perm_seed is not None else None
     keys = []
@@ -156,23 +155,35 @@ def rmat_row_block(n, n_edges, r0, r1, seed=42, perm_seed=43, device="cpu", coun
         if perm is not None:
             src, dst = perm[src], perm[dst]
         keep = (src >= r0) & (src < r1)
-        keys.append(torch.unique((src[keep] - r0) * n + dst[keep]))   # (chunk-local dedupe)
+        keys.append(torch.unique(src[keep] * n + dst[keep]))          # (chunk-local dedupe)
     del perm
     diag = torch.arange(r0, r1, device=device, dtype=torch.int64)
-    key = torch.unique(torch.cat(keys + [(diag - r0) * n + diag]))
-    del keys
-    row = key // n
+    return torch.unique(torch.cat(keys + [diag * n + diag]))
+
+
+def csr_from_keys(key, n, r0, r1):
+    """Sorted unique global keys row·n + col of rows [r0, r1) -> (rowptr rebased to 0, col global
+    ids int32, val fp32 = 1 / stored entries of the row): D^-1(A + I) for a 0/1 adjacency."""
+    row = key // n - r0
     deg = torch.bincount(row, minlength=r1 - r0)
-    if counts_only:
-        return deg
-    col = (key - row * n).to(torch.int32)
-    del key
-    rowptr = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=device)
+    col = (key - (row + r0) * n).to(torch.int32)
+    rowptr = torch.zeros(r1 - r0 + 1, dtype=torch.int64, device=key.device)
     torch.cumsum(deg, 0, out=rowptr[1:])
     val = (1.0 / deg.to(torch.float32))[row]
     if col.numel() < 2 ** 31 - 1:
         rowptr = rowptr.to(torch.int32)
     return rowptr, col, val
+
+
+def rmat_row_block(n, n_edges, r0, r1, seed=42, perm_seed=43, device="cpu", counts_only=False):
+    """Rows [r0, r1) of the SAME normalized adjacency `rmat_graph(n, n_edges, seed, perm_seed)`
+    builds, generated without ever holding the other rows (rmat_block_keys).  Returns
+    (rowptr rebased to 0, col global ids int32, val fp32); with `counts_only` just the stored
+    entries per row (int64 [r1 - r0]) — all a partitioner needs."""
+    key = rmat_block_keys(n, n_edges, r0, r1, seed, perm_seed, device)
+    if counts_only:
+        return torch.bincount(key // n - r0, minlength=r1 - r0)
+    return csr_from_keys(key, n, r0, r1)
 
 
 def normalized_adjacency_csr(src, dst, n, perm_seed=43):

@@ -62,7 +62,7 @@ def _cpu_bwd_with_hint(grad_out, out, relu, scale, want_bias):
 
 
 def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False, build="global",
-            overlap=True):
+            overlap=True, static_rows=False, compress=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -77,13 +77,23 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
         fin, nhid, ncls = 24, 32, 16
         rowptr, col, val = rmat_graph(n, n_edges, seed=5, device="cpu")   # same on every rank
         kw = dict(exchange=exchange, graph_factory=_CpuGraph, spmm_fn=_cpu_spmm, overlap=overlap,
-                  bwd_fn=_cpu_bwd_with_hint if bitmap_hint else _cpu_bwd)
+                  bwd_fn=_cpu_bwd_with_hint if bitmap_hint else _cpu_bwd, compress_hidden=compress)
         if build == "global":
             sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, **kw)
         else:
             # shard-local construction: this rank generates only its own rows, the transpose
             # blocks come from the triplet exchange — must give exactly the blocks of the global build
-            sg = ShardedGraph.from_rmat(n, n_edges, rank, world, "cpu", seed=5, **kw)
+            import pygcn_amd.utils as U
+            passes, real_chunks = [], U.rmat_edge_chunks
+            U.rmat_edge_chunks = lambda *a_, **k_: (passes.append(1), real_chunks(*a_, **k_))[1]
+            try:
+                sg = ShardedGraph.from_rmat(n, n_edges, rank, world, "cpu", seed=5, **kw)
+            finally:
+                U.rmat_edge_chunks = real_chunks
+            # ONE replay of the edge stream per rank; rows that changed owner between the provisional
+            # uniform blocks and the nnz-balanced ones travelled point to point
+            assert len(passes) == 1 and sg.setup_stats["edge_stream_passes"] == 1
+            assert sg.setup_stats["entries_received_in_rebalance"] >= 0
             ref = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, **kw)
             assert sg.bounds == ref.bounds
             for a, b in ((sg.A, ref.A), (sg.At, ref.At)):
@@ -103,7 +113,14 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
         model.train()
         x_loc, y_loc = x[sg.r0:sg.r1], labels[sg.r0:sg.r1]
         idx_loc = train[(train >= sg.r0) & (train < sg.r1)] - sg.r0
+        if static_rows:           # (flag on every rank alike: it selects the exchange protocol)
+            smodel.declare_loss_rows(idx_loc)
         logp = smodel(x_loc, sg)
+        if compress:
+            # layer 2's input rows (ReLU output: about half zeros here) travelled as bitmask + values
+            assert sg.compress_hidden
+            dense_bytes = sg.halo.n_halo * nhid * 4
+            assert sg.halo.n_halo == 0 or 0 < sg.last_recv_bytes["fwd"] < 0.75 * dense_bytes
         loss = smodel.nll_loss(logp, y_loc, idx_loc)
         loss.backward()
         smodel.allreduce_grads()
@@ -137,6 +154,9 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
             smodel.nll_loss(smodel(x_loc, sg), y_loc, idx_loc).backward()
             smodel.allreduce_grads()
             assert sg.n_const_exchanges == 1
+            # count exchanges (all-gather + host read) of the row-sparse gradient exchange: one per
+            # step by default, ONE IN TOTAL once the loss rows are declared (static structure)
+            assert sg.halo_t.n_count_exchanges == (1 if static_rows else 2)
             for k, v in model.named_parameters():
                 assert torch.equal(v.grad, first[k]), k
             x_loc.mul_(1.0)
@@ -196,6 +216,27 @@ def test_sparse_gradient_exchange_with_bitmap_hint(tmp_path, oracle):
     mp.spawn(_worker, args=(3, _free_port(), 4000, 30000, str(tmp_path), "halo", True), nprocs=3,
              join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_declared_loss_rows_make_the_gradient_exchange_static(world, tmp_path, oracle):
+    """ShardedGCN.declare_loss_rows: the layer-by-layer path's row-sparse backward exchange runs
+    its count exchange once instead of every step — same gradients (oracle parity in the worker)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), 4000, 30000, str(tmp_path), "halo", False, "global",
+                            True, True), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_compressed_hidden_layer_exchange(world, tmp_path, oracle):
+    """ShardedGraph(compress_hidden=True): the halo rows of a hidden activation travel as bitmask +
+    non-zero values and meet the weight on arrival (product_hidden / ShardedHiddenLayerFunction);
+    same forward values and gradients as the unsharded oracle, fewer bytes than dense rows."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), 4000, 30000, str(tmp_path), "halo", False, "global",
+                            True, False, True), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
 def test_partition_and_remap_are_consistent():

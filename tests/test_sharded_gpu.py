@@ -66,12 +66,12 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, build="global"):
         ref.train()
         g = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), (n, n))
 
-        def keep(m, i, o):
-            h1["ref"] = o.detach()
-            o.register_hook(lambda gr: h1.__setitem__("ref_grad", gr.detach()))
-        hook = ref.gc1.register_forward_hook(keep)
-        rl = ref(x.to(dev), g)
-        hook.remove()
+        # (composed from its two layers by hand: the hidden activation and its gradient are needed
+        #  below, and `ref(x, g)` runs as ONE autograd node whose inside no module hook sees)
+        hid = ref.gc1(x.to(dev), g, relu=True)
+        h1["ref"] = hid.detach()
+        hid.register_hook(lambda gr: h1.__setitem__("ref_grad", gr.detach()))
+        rl = ref.gc2(hid, g, log_softmax=True)
         rloss = torch.nn.functional.nll_loss(rl, labels.to(dev))
         rloss.backward()
 
