@@ -299,6 +299,28 @@ static_assert(kH2StageBytes % (16 * kThreads) == 0, "W stage must divide over th
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+// X THROUGH LDS BY DMA (round 3).  The MFMA wants a lane to own 8 consecutive k of ONE row, so a
+// wave's direct global loads touch 32 different rows per instruction: 64 L1 tag look-ups for 1 KiB
+// (profiles/r02_gemm_pmc.md).  With GEMM_H2_XLDS the X tile of a wave travels HBM -> LDS by
+// `global_load_lds_dwordx4` (no VGPRs, asynchronous), in chunks of 32 rows x 32 columns (2 K steps):
+// four instructions per chunk, in each of which every QUAD of lanes reads 64 contiguous bytes of
+// one row (16 look-ups per KiB: the coalesced count).  The LDS position of a lane's 16 bytes is
+// fixed by its lane id (base + 16·lane), but WHICH (row, columns) a lane fetches is free — the
+// assignment below makes the later fragment reads (ds_read_b128, lane = MFMA row) conflict-free:
+//   instruction j (0..3), lane l: quad Q = l >> 2, p = l & 3;  t = Q & 3, half = (Q >> 2) & 1,
+//   cstep = Q >> 3;   row = 16·half + 4·j + t,   columns 32·chunk + 16·cstep + 4·p .. +3,
+//   LDS byte = j·1040 + 16·l          (1040 = 1 KiB + one 16-byte slot: slot index ≡ j mod 16)
+// MFMA lane (i, h) of K step cstep reads 32 bytes at  (i>>2 & 3)·1040 + 16·(4·(4·(i>>4) + (i&3) +
+// 8·cstep) + 2·h): for the 16 lanes of a read phase the slot index mod 16 is j + 4·t + const —
+// sixteen different bank groups.
+#ifndef GEMM_H2_XLDS
+#define GEMM_H2_XLDS 1          /* 0: round 2's pipeline (X and W through VGPRs) — kept for A/B builds */
+#endif
+constexpr int kXInstrBytes = 1024 + 16;
+constexpr int kXChunkBytes = 4 * kXInstrBytes;            // 32 rows x 32 columns fp32, padded
+constexpr int kXRing = 2;                                  // chunks per wave: one in use, one in flight
+constexpr int kXLdsBytes = GEMM_H2_XLDS ? kWaves * kXRing * kXChunkBytes : 0;
+
 // exponent e with 2^e <= v < 2^(e+1) for finite v > 0 (0 for zero / non-finite: no scaling)
 __device__ __forceinline__ int floor_log2f(float v)
 {
@@ -409,6 +431,24 @@ __device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// 16 bytes per lane straight from global memory into LDS (asynchronous, counted by vmcnt like a
+// load): the wave's 64 x 16 bytes land contiguously at LDS byte address `lds_addr` (wave-uniform,
+// through M0).  Issued as inline assembly ON PURPOSE (GEMM_H2_XLDS): hipcc's wait-count pass
+// treats every LDS access after a `__builtin_amdgcn_global_load_lds` as dependent on it and drains
+// the whole prefetch with `s_waitcnt vmcnt(0)`; here the kernel places its own counted waits
+// (dma_wait<N>: N = DMA instructions issued AFTER the youngest one that must have landed — vector
+// loads complete in order, so "at most N outstanding" means everything older is in LDS; stores
+// that complete early only make the wait longer, never shorter).
+__device__ __forceinline__ void dma16(const void *g, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(g), "s"(lds_addr) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void dma_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
 // FWD_EPI = false: plain product / backward mask, persistent with the cross-tile pipeline.
 // FWD_EPI = true: bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
 // the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
@@ -429,7 +469,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // indices; kChunks % kH2Ring == 0 keeps slot = step % kH2Ring valid across the boundary.
     static_assert(kChunks % kH2Ring == 0, "the X ring must divide the K steps of a tile");
     static_assert(kChunks % kStage == 0 && (kChunks / kStage) % 2 == 0, "W stages must alternate evenly");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];     // the two W stages
+#if GEMM_H2_XLDS
+    // (a separate LDS object, so the compiler's wait-count pass can tell a DMA into an X ring from
+    //  a store into a W stage and does not drain the X prefetch at every W stage)
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];              // X rings, per wave
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned char *wimg = ws + kH2HeaderBytes;
     const int64_t n_tiles = (M + kTileRows - 1) / kTileRows;
@@ -451,24 +496,64 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
     const float back_b = pow2f(back - back / 2);                      // exact steps
 
+#if GEMM_H2_XLDS
+    static_assert(kStage == 2 && kWaves == 8, "the DMA pipeline is written for 2-step W stages and 8 waves");
+    const unsigned char *wl = wimg;
+    const uint32_t w_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds +
+                           __builtin_amdgcn_readfirstlane(wave) * (kH2StageBytes / kWaves);
+    // this wave's eighth (4 KiB = 4 DMA instructions) of W stage `st` -> W buffer `b`
+    auto w_issue = [&](int st, int b) {
+        const unsigned char *src = wl + (size_t)st * kH2StageBytes + wave * (kH2StageBytes / kWaves) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(src + i * 1024, w_lds + b * kH2StageBytes + i * 1024);
+    };
+#else
     u32x4 wreg[kH2WLoads];
     const unsigned char *wl = wimg;     // (re-made opaque per tile, see the tile loop)
-    auto w_load = [&](int st) {
+#endif
+    [[maybe_unused]] auto w_load = [&](int st) {
         const u32x4 *src = (const u32x4 *)(wl + (size_t)st * kH2StageBytes);
+#if !GEMM_H2_XLDS
 #pragma unroll
         for (int i = 0; i < kH2WLoads; ++i) wreg[i] = src[i * kThreads + tid];
+#else
+        (void)src;
+#endif
     };
-    auto w_store = [&](int b) {
+    [[maybe_unused]] auto w_store = [&](int b) {
+#if !GEMM_H2_XLDS
         u32x4 *dst = (u32x4 *)(lds + b * kH2StageBytes);
 #pragma unroll
         for (int i = 0; i < kH2WLoads; ++i) dst[i * kThreads + tid] = wreg[i];
+#else
+        (void)b;
+#endif
     };
+#if GEMM_H2_XLDS
+    unsigned char *xl = xlds + __builtin_amdgcn_readfirstlane(wave) * (kXRing * kXChunkBytes);
+    // (what this lane FETCHES in instruction j of a chunk, and where this MFMA lane READS)
+    const int ld_row0 = 16 * ((lane >> 4) & 1) + ((lane >> 2) & 3);       // + 4·j
+    const int ld_col = 16 * (lane >> 5) + 4 * (lane & 3);                 // + 32·chunk
+    const int rd_off = (((lane & 31) >> 2) & 3) * kXInstrBytes +
+                       16 * (4 * (4 * ((lane & 31) >> 4) + (lane & 3)) + 2 * (lane >> 5));   // + 512·cstep
+    auto x_issue = [&](const float *const (&src)[4], int chunk, int slot) {
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)xl + slot * kXChunkBytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(src[j] + 32 * chunk, base + j * kXInstrBytes);
+    };
+    auto a_read = [&](int cstep, int slot, f32x4 &lo, f32x4 &hi) {
+        const unsigned char *q = xl + slot * kXChunkBytes + rd_off + 512 * cstep;
+        lo = *(const f32x4 *)q;
+        hi = *(const f32x4 *)(q + 16);
+    };
+#else
     f32x4 ar[kH2Ring][2];      // X fragments: this step + (kH2Ring - 1) steps of prefetch
     auto a_fetch = [&](const float *xr, int c, f32x4 &lo, f32x4 &hi) {
         const f32x4 *p = (const f32x4 *)(xr + c * kChunk);
         lo = p[0];
         hi = p[1];
     };
+#endif
     u32x4 Ah, Am;
     auto split_frag = [&](const f32x4 &lo, const f32x4 &hi, bool ok) {
         const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -500,12 +585,36 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     int64_t row, src_row;
     bool row_ok;
     tile_rows(tile, row, row_ok, src_row);
+#if GEMM_H2_XLDS
+    // the four rows this lane fetches per chunk (one per DMA instruction), as row pointers
+    auto load_rows = [&](int64_t t, const float *(&src)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = t * kTileRows + 32 * wave + ld_row0 + 4 * j;
+            const bool ok = t < n_tiles && r < M;
+            const int64_t sr = ok ? (x_rows ? (int64_t)x_rows[r] : r) : 0;
+            src[j] = X + sr * ldx + ld_col;
+        }
+    };
+    const float *xsrc[4];
+    load_rows(tile, xsrc);
+    x_issue(xsrc, 0, 0);
+    w_issue(0, 0);
+    x_issue(xsrc, 1, 1);
+    dma_wait<4>();                 // X chunk 0 and this wave's part of W stage 0 are in LDS
+    {
+        f32x4 lo, hi;
+        a_read(0, 0, lo, hi);
+        split_frag(lo, hi, row_ok);
+    }
+#else
     const float *xrow = X + src_row * ldx + 8 * (lane >> 5);
     w_load(0);
 #pragma unroll
     for (int c = 0; c < kH2Ring - 1; ++c) a_fetch(xrow, c, ar[c][0], ar[c][1]);
     w_store(0);
     split_frag(ar[0][0], ar[0][1], row_ok);
+#endif
     uint32_t vmax = 0u;   // max of |y| as BITS: unsigned order = float order for finite values, and
                           // inf / NaN patterns sort above every finite one (an overflow is never lost)
 
@@ -520,7 +629,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         int64_t row_n, src_n;
         bool ok_n;
         tile_rows(tile + gridDim.x, row_n, ok_n, src_n);
+#if GEMM_H2_XLDS
+        const float *xsrc_n[4];
+        load_rows(tile + gridDim.x, xsrc_n);
+#else
         const float *xrow_n = X + src_n * ldx + 8 * (lane >> 5);
+#endif
         f32x16 acc[8];
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
@@ -529,6 +643,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             const int st = c / kStage;
+#if GEMM_H2_XLDS
+            if (c % kStage == 0) {
+                // every wave waited for ITS part of W stage st before it got here (end of the
+                // previous stage / prologue) and has read its last fragment of stage st - 1
+                __builtin_amdgcn_s_barrier();
+                if ((st + 1) * kStage < kChunks)
+                    w_issue(st + 1, (st + 1) & 1);
+                else if (has_next)
+                    w_issue(0, 0);                                // the next tile's first stage
+            }
+#else
             if (c % kStage == 0) {
                 __syncthreads();
                 if ((st + 1) * kStage < kChunks)
@@ -536,6 +661,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 else if (has_next)
                     w_load(0);                                    // the next tile's first stage
             }
+#endif
+#if GEMM_H2_XLDS
+            if (c & 1) {
+                // chunk m = (c + 3) / 2 goes into the ring slot chunk m - 2 has just left (its last
+                // fragment was read at the end of step c - 1): three K steps of flight time
+                constexpr int kCh = kChunks / 2;
+                const int m = (c + 3) / 2;
+                if (m < kCh)
+                    x_issue(xsrc, m, m & 1);
+                else if (has_next)
+                    x_issue(xsrc_n, m - kCh, m & 1);
+            }
+#else
             {
                 constexpr int R = kH2Ring;
                 const int fc = c + R - 1;                         // step fetched now
@@ -544,6 +682,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 else if (has_next)
                     a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
             }
+#endif
             const u32x4 Xh = Ah, Xm = Am;
             const unsigned char *buf = lds + (st & 1) * kH2StageBytes + (c % kStage) * kH2ChunkBytes;
             u32x4 Bf[2][2];
@@ -564,12 +703,35 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 __builtin_amdgcn_s_setprio(0);
                 acc[nb] = t;
             }
+#if GEMM_H2_XLDS
+            if (c % kStage == kStage - 1) {
+                // before the next stage: this wave's part of W stage st + 1 and X chunk st + 1 (the
+                // next K step's fragment) must be in LDS.  Younger than both: only the 4 DMA
+                // instructions of X chunk st + 2, issued at the top of this step — if they were.
+                constexpr int kCh = kChunks / 2;
+                const bool issued_x = ((c + 3) / 2 < kCh) || has_next;
+                if (c + 1 < kChunks || has_next) {
+                    if (issued_x) dma_wait<4>();
+                    else dma_wait<0>();
+                }
+            }
+#else
             if (c % kStage == kStage - 1) {
                 if (c + 1 < kChunks)
                     w_store((st + 1) & 1);
                 else if (has_next)
                     w_store(0);              // (stage kChunks/kStage would use buffer 0 too)
             }
+#endif
+#if GEMM_H2_XLDS
+            if (c + 1 < kChunks || has_next) {
+                const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
+                f32x4 lo, hi;
+                a_read(cn & 1, (cn >> 1) & 1, lo, hi);
+                split_frag(lo, hi, c + 1 < kChunks ? row_ok : ok_n);
+                asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#else
             if (c + 1 < kChunks) {
                 split_frag(ar[(c + 1) % kH2Ring][0], ar[(c + 1) % kH2Ring][1], row_ok);
                 asm volatile("" : "+v"(Ah), "+v"(Am));
@@ -577,6 +739,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 split_frag(ar[0][0], ar[0][1], ok_n);
                 asm volatile("" : "+v"(Ah), "+v"(Am));
             }
+#endif
         }
 
         if (row_ok) {
@@ -654,7 +817,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         row = row_n;
         row_ok = ok_n;
         src_row = src_n;
+#if GEMM_H2_XLDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xsrc[j] = xsrc_n[j];
+#else
         xrow = xrow_n;
+#endif
     }
     if (y_absmax != nullptr) {                 // |y| >= 0: float order == unsigned order of the bits
 #pragma unroll
@@ -1203,15 +1371,29 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
+    // dynamic LDS of the X-through-LDS build: the two W stages + every wave's X ring (> 64 KiB)
+    const size_t dyn = GEMM_H2_XLDS ? (size_t)kXLdsBytes : 0;
+    if (dyn) {
+        static bool raised = false;          // (idempotent; a benign race sets it twice)
+        if (!raised) {
+            hipError_t a1 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipError_t a2 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            if (a1 != hipSuccess || a2 != hipSuccess)
+                return gcn_internal_fail_hip((int)(a1 != hipSuccess ? a1 : a2), "gcn_gemm_xw256_f32_h2: LDS size");
+            raised = true;
+        }
+    }
     if (ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u) {
         const unsigned egrid = GEMM_H2_EPI_PERSIST ? (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID)
                                                    : (unsigned)tiles;
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3(egrid), dim3(kThreads), 0, s, X, ldx,
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3(egrid), dim3(kThreads), dyn, s, X, ldx,
                            x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                            (uint32_t *)y_absmax, ep);
     } else {
         const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<false>, dim3(grid), dim3(kThreads), 0, s, X, ldx,
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<false>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
                            x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                            (uint32_t *)y_absmax, ep);
     }
