@@ -493,8 +493,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     }
     const float xs = pow2f(x_exp);
     const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
-    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
-    const float back_b = pow2f(back - back / 2);                      // exact steps
+    // (one multiply when 2^back is a normal float — always, outside the edges of fp32 —, else two)
+    const bool one_step = back >= -126 && back <= 127;
+    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(one_step ? back : back / 2);
+    const float back_b = one_step ? 1.f : pow2f(back - back / 2);    // exact steps
 
 #if GEMM_H2_XLDS
     static_assert(kStage == 2 && kWaves == 8, "the DMA pipeline is written for 2-step W stages and 8 waves");
@@ -754,8 +756,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 uint32_t r4[4] = {0u, 0u, 0u, 0u};     // the 8 keep fields of a pair of column groups
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[nb][4 * g] * back_a * back_b, acc[nb][4 * g + 1] * back_a * back_b,
-                               acc[nb][4 * g + 2] * back_a * back_b, acc[nb][4 * g + 3] * back_a * back_b};
+                    f32x4 v = {acc[nb][4 * g] * back_a, acc[nb][4 * g + 1] * back_a,
+                               acc[nb][4 * g + 2] * back_a, acc[nb][4 * g + 3] * back_a};
+                    if (!one_step) {                                           // (wave-uniform, rare)
+                        v.x *= back_b; v.y *= back_b; v.z *= back_b; v.w *= back_b;
+                    }
                     // forward epilogue of the layer when the GEMM is its LAST stage
                     // ((Â·X)·W + b, pygcn/layers.py:33-36 reassociated): bias, ReLU, inverted dropout
                     const int f = 32 * nb + 8 * g + 4 * (lane >> 5);          // first of 4 columns
@@ -806,8 +811,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     if (v.x == 1.2345e-30f)
 #endif
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
-                    vmax = max(max(vmax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu)),
-                               max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+                    if (y_absmax != nullptr) {                                 // (wave-uniform)
+                        if (FWD_EPI && ep.relu)      // stored values are >= 0 (or NaN): the bits as they are
+                            vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
+                                       max(__float_as_uint(v.z), __float_as_uint(v.w)));
+                        else
+                            vmax = max(max(vmax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu)),
+                                       max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+                    }
                     // (keeps hipcc from running all 32 Philox chains of the tile side by side —
                     //  128 live registers on top of the accumulators)
                     if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
