@@ -906,6 +906,9 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
         const int64_t row = t * 32 + r;
         if (row < M) {
             unsigned char *yrow = (unsigned char *)(Y + row * ldy) + (h ? 16 : 0);
+            const uint16_t *mrow = (!FWD_EPI && ep.mask_src != nullptr)
+                ? (const uint16_t *)ep.mask_src + (ep.mask_rows ? (int64_t)ep.mask_rows[row] : row) * ep.ld_mask
+                : nullptr;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -952,6 +955,20 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[nb][4 * gg + j] = v[j];
+                        }
+                    }
+                    if (!FWD_EPI && ep.mask_src != nullptr) {              // (uniform branch)
+                        // backward of a fused ReLU / dropout epilogue in the grad_input GEMM's own
+                        // store: y = mask > 0 ? y * scale : 0, the mask (bf16 activations of the
+                        // layer below) read at this lane's 4 columns of each group through the row
+                        // list — no compacting copy of the mask rows, no extra elementwise pass
+#pragma unroll
+                        for (int gg = g; gg < g + 2; ++gg) {
+                            const uint2 mk = *(const uint2 *)(mrow + 32 * nb + 8 * gg + 4 * h);
+                            const uint32_t mb[4] = {mk.x << 16, mk.x & 0xffff0000u, mk.y << 16, mk.y & 0xffff0000u};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[nb][4 * gg + j] = __uint_as_float(mb[j]) > 0.f ? acc[nb][4 * gg + j] * ep.mask_scale : 0.f;
                         }
                     }
                     // groups k = 4nb + g and k + 1: this lane's 4 columns of each, packed to bf16
@@ -1429,8 +1446,16 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: dropout_p must be in [0, 1)");
         if (epi->dropout_p > 0.f && !epi->relu)
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: dropout needs relu (out > 0 encodes the mask)");
-        if (epi->mask_src != nullptr)
-            return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: no backward mask at bf16");
+        if (epi->mask_src != nullptr) {
+            if (epi->bias != nullptr || epi->relu || epi->dropout_p > 0.f)
+                return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: forward epilogue and backward mask exclude each other");
+            if (((uintptr_t)epi->mask_src) % 8 != 0 || epi->ld_mask % 4 != 0 || epi->ld_mask < N)
+                return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: mask rows must be 8-byte aligned bf16 [*, N]");
+            ep.mask_src = (const float *)epi->mask_src;      // (bf16 data; typed per kernel)
+            ep.ld_mask = epi->ld_mask;
+            ep.mask_rows = epi->mask_rows;
+            ep.mask_scale = epi->mask_scale;
+        }
         if (((uintptr_t)epi->bias) % 16 != 0)
             return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: bias must be 16-byte aligned");
         ep.bias = epi->bias;

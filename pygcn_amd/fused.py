@@ -242,6 +242,8 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     w2t = w2.t().contiguous()
     gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_rows=rs.rows2_i32,
                        mask_scale=ctx.scale) if fast else None
+    if gpre1 is None and dt == torch.bfloat16:       # (C5: the bf16 GEMM carries the mask too)
+        gpre1 = _spmm.gemm_bf16(grad_sup2, w2t, mask_src=h1, mask_rows=rs.rows2_i32, mask_scale=ctx.scale)
     if gpre1 is None:
         h1c = h1.index_select(0, rs.rows2) if h1c is None else h1c
         gh1 = _dense_forward(grad_sup2, w2t, gs_bound, gh_max)

@@ -463,12 +463,16 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     return Y
 
 
-def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0, row_base=0):
+def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0, row_base=0, mask_src=None,
+              mask_rows=None, mask_scale=1.0):
     """X[M,K] · W[K,N] for bf16 storage through the streaming MFMA kernel (C-ABI gcn_gemm_xw_bf16;
     (K, N) in {(128,128), (128,256), (256,128)} — config C5's layers are 128 -> 128).
     `bias` / `relu` / `dropout_p` / `seed`: the layer's FORWARD epilogue on the fp32 accumulators
     before the rounding to bf16 (same Philox keep function as the SpMM epilogue) — for a layer
-    evaluated as (Â·X)·W + b.  None if the operands do not fit (the caller then uses torch.mm)."""
+    evaluated as (Â·X)·W + b.  `mask_src` (bf16 [*, N], read at row mask_rows[r] — an int32 device
+    list — or r for output row r): the store becomes mask_src > 0 ? y * mask_scale : 0, the backward
+    of a fused ReLU / dropout epilogue in the grad_input GEMM's own store (excludes the forward
+    epilogue).  None if the operands do not fit (the caller then uses torch.mm)."""
     if (X.dtype != torch.bfloat16 or W.dtype != torch.bfloat16 or not X.is_cuda or X.dim() != 2
             or W.dim() != 2 or X.shape[1] != W.shape[0] or X.shape[0] == 0 or X.stride(1) != 1
             or W.stride(1) != 1 or X.stride(0) % 8 or X.data_ptr() % 16):
@@ -479,7 +483,17 @@ def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0, row_base=0):
     if ws_bytes == 0:
         return None
     ep = bias32 = None
-    if bias is not None or relu or dropout_p > 0.0:
+    if mask_src is not None:
+        if (bias is not None or relu or dropout_p > 0.0 or mask_src.dtype != torch.bfloat16
+                or mask_src.dim() != 2 or mask_src.shape[1] != N or mask_src.stride(1) != 1
+                or mask_src.stride(0) % 4 or mask_src.data_ptr() % 8 or mask_src.device != X.device):
+            return None
+        if mask_rows is not None and (mask_rows.dtype != torch.int32 or not mask_rows.is_contiguous()
+                                      or mask_rows.device != X.device or mask_rows.numel() < X.shape[0]):
+            raise RuntimeError("gemm_bf16: mask_rows must be a contiguous int32 device list, one entry per output row")
+        ep = _native.GcnGemmEpilogue(None, 0, 0.0, 0, None, mask_src.data_ptr(), mask_src.stride(0),
+                                     float(mask_scale), mask_rows.data_ptr() if mask_rows is not None else None, 0)
+    elif bias is not None or relu or dropout_p > 0.0:
         if bias is not None:
             if bias.numel() != N or bias.device != X.device:
                 return None

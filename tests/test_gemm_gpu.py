@@ -405,3 +405,29 @@ def test_bf16_weight_gradient_over_row_lists(dev, m, listed):
     assert torch.equal(got, again)
     # shapes the kernel does not carry decline (the caller falls back to a library GEMM)
     assert weight_grad_rows(A[:, :64], G[:, :64]) is None
+
+
+def test_bf16_gemm_with_backward_mask_in_the_store(dev):
+    """gcn_gemm_xw_bf16 with `mask_src` / `mask_rows`: the backward of a fused ReLU / dropout epilogue
+    (y = mask > 0 ? y * scale : 0) in the grad_input GEMM's own store at bf16 (config C5), the mask
+    read through a row list — against the unfused composition on the same bf16 values."""
+    from pygcn_amd.spmm import gemm_bf16
+    torch.manual_seed(5)
+    M, n = 7001, 30000
+    X = torch.randn(M, 128, device=dev).bfloat16()
+    W = (torch.randn(128, 128, device=dev) * 0.1).bfloat16()
+    H = torch.relu(torch.randn(n, 128, device=dev)).bfloat16()            # ~half zeros, like h1
+    rows = torch.randint(0, n, (M,), device=dev, dtype=torch.int32)
+    plain = gemm_bf16(X, W)
+    got = gemm_bf16(X, W, mask_src=H, mask_rows=rows, mask_scale=2.0)
+    assert got is not None and got.dtype == torch.bfloat16
+    acc = X.float() @ W.float()
+    want = torch.where(H[rows.long()] > 0, acc * 2.0, torch.zeros_like(acc)).bfloat16()
+    assert torch.equal(got == 0, want == 0) or ((got == 0) != (want == 0)).sum() <= 2      # (products that round to 0)
+    err = (got.float() - want.float()).abs().max().item()
+    assert err <= 2.0 ** -7 * want.float().abs().max().item()
+    # without a row list the mask row is the output row; and the mask excludes the forward epilogue
+    got2 = gemm_bf16(X, W, mask_src=H[:M].contiguous(), mask_scale=1.0)
+    want2 = torch.where(H[:M] > 0, plain.float(), torch.zeros_like(acc))
+    assert (got2.float() - want2).abs().max().item() <= 2.0 ** -7 * want2.abs().max().item()
+    assert gemm_bf16(X, W, relu=True, mask_src=H[:M].contiguous()) is None
