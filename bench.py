@@ -418,7 +418,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         if reference_call:      # upstream's literal lines (train.py:140-157): no `rows=` hint
             out = fwd_model(x, adj)
-            loss = F.nll_loss(out[idx_train].float(), labels_train)
+            loss = F.nll_loss(out[idx_train], labels_train)
         elif world > 1 and dense_loss:
             out = fwd_model(x, adj)
             loss = fwd_model.nll_loss(out.float(), labels, None)

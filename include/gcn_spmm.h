@@ -270,7 +270,8 @@ int gcn_relu_dropout_backward_colsum(int dtype, const void *grad_out, const void
  * non-zero per row, grad_out[r][target[r]] = *coef (coef = -upstream / n_rows, DEVICE float), so it
  * is never materialised: grad_pre = *coef * (onehot(target[r]) - exp(out[r])) and its column sums
  * come straight from `out` (log-probabilities, [n_rows, F]) and the label vector `target` (DEVICE
- * int64 [n_rows], entries in [0, F); an entry outside that range contributes no onehot term).
+ * int64 [n_rows], entries in [0, F); a NEGATIVE entry marks an ignored row — torch's ignore_index =
+ * -100 — whose gradient row is zero; the caller's coef then divides by the rows that count).
  * 2 full-height streams (read out, write grad_pre) instead of 4.  Shape rules and scratch of
  * gcn_log_softmax_backward_colsum.  (ABI 22.)
  */

@@ -931,11 +931,16 @@ __global__ __launch_bounds__(256) void bwd_colsum_kernel(const T *__restrict__ g
         if (MODE != 3) Elem<T, VEC>::unpack(*(const Raw *)(grad_out + off), g);
         Raw packed = {};
         if (MODE == 3) {
-            const int64_t t = target[r] - VEC * cg;   // (one address per row: a broadcast load)
-            float o[VEC];
-            Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+            const int64_t t_row = target[r];          // (one address per row: a broadcast load)
+            const int64_t t = t_row - VEC * cg;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) g[i] = cf * ((t == i ? 1.f : 0.f) - expf(o[i]));
+            for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+            if (t_row >= 0) {   // a negative label (torch's ignore_index = -100) is an ignored row: zeros
+                float o[VEC];
+                Elem<T, VEC>::unpack(*(const Raw *)(out + off), o);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] = cf * ((t == i ? 1.f : 0.f) - expf(o[i]));
+            }
             packed = Elem<T, VEC>::pack(g);
             Elem<T, VEC>::unpack(packed, g);
         }

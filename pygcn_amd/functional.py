@@ -11,7 +11,7 @@ import torch.utils._pytree as pytree
 
 class NLLGrad(torch.Tensor):
     """The gradient of a mean NLL loss with respect to its [n, C] input: ONE non-zero per row,
-    `coef` (device float32 [1]) at column target[r].  A wrapper tensor without storage, like
+    `coef` (device float32 [1]) at column target[r] (a negative target marks an ignored row: zeros).  A wrapper tensor without storage, like
     rowgrad.RowGrad: the model's one-node backward pass (pygcn_amd/fused.py) recognises it and
     forms coef·(onehot − exp(logp)) in one sweep without the [n, C] gradient ever existing
     (10 GB at config C4); every other consumer sees the dense tensor (any operator on it
@@ -27,7 +27,9 @@ class NLLGrad(torch.Tensor):
     def dense(self):
         n = self.shape[0]
         out = torch.zeros(tuple(self.shape), dtype=self.dtype, device=self.device)
-        return out.scatter_(1, self.target.view(-1, 1), self.coef.to(self.dtype).expand(n, 1))
+        keep = self.target >= 0                                   # (negative label = ignored row)
+        safe = torch.where(keep, self.target, torch.zeros_like(self.target))
+        return out.scatter_(1, safe.view(-1, 1), (self.coef.to(self.dtype) * keep).view(n, 1))
 
     def __repr__(self):
         return f"NLLGrad(shape={tuple(self.shape)}, dtype={self.dtype})"
@@ -40,30 +42,39 @@ class NLLGrad(torch.Tensor):
 
 class _NLLMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, log_probs, target, structural=False):
+    def forward(ctx, log_probs, target, structural=False, ignore_index=-100):
         if log_probs.dim() != 2 or target.dim() != 1 or target.shape[0] != log_probs.shape[0]:
             raise RuntimeError("nll_loss: expected log_probs [n, C] and target [n]")
         ctx.structural = bool(structural)
-        ctx.save_for_backward(target)
         ctx.shape, ctx.dtype = log_probs.shape, log_probs.dtype
-        picked = log_probs.gather(1, target.view(-1, 1)).float()
-        return -picked.mean()
+        # `ignore_index` exactly as torch: such rows add nothing and do not count in the mean
+        # (elementwise work on [n] only; no host synchronisation)
+        keep = target != ignore_index
+        safe = torch.where(keep, target, torch.zeros_like(target))
+        picked = log_probs.gather(1, safe.view(-1, 1)).float().squeeze(1)
+        count = keep.sum().float()
+        ctx.save_for_backward(safe, keep, count)
+        return -(picked * keep).sum() / count
 
     @staticmethod
     def backward(ctx, grad):
-        (target,) = ctx.saved_tensors
+        safe, keep, count = ctx.saved_tensors
         n = ctx.shape[0]
         if ctx.structural and grad.is_cuda and n > 0:   # nothing of size [n, C] is written here
-            return NLLGrad(target, (-grad / n).float().reshape(1), ctx.shape, ctx.dtype), None, None
+            # (rows carrying the — negative — ignore_index keep their negative label: the consumer
+            #  gives them a zero gradient row, and `count` excludes them)
+            return NLLGrad(torch.where(keep, safe, torch.full_like(safe, -1)),
+                           (-grad / count).float().reshape(1), ctx.shape, ctx.dtype), None, None, None
         g = torch.zeros(ctx.shape, dtype=ctx.dtype, device=grad.device)
-        g.scatter_(1, target.view(-1, 1), (-grad / n).to(ctx.dtype).expand(n, 1))
-        return g, None, None
+        coef = ((-grad / count).float() * keep).to(ctx.dtype).view(n, 1)
+        g.scatter_(1, safe.view(-1, 1), coef)
+        return g, None, None, None
 
 
-def nll_loss(log_probs, target):
+def nll_loss(log_probs, target, ignore_index=-100):
     """Drop-in for `torch.nn.functional.nll_loss(log_probs, target)` (mean over the rows, no class
-    weights, no ignore_index) — the form the reference's training step uses.  fp32 or bf16
-    log-probabilities (the loss value is fp32 either way).
+    weights; `ignore_index` as in torch) — the form the reference's training step uses
+    (pygcn/train.py:153).  fp32 or bf16 log-probabilities (the loss value is fp32 either way).
 
     When `log_probs` is the model's own full output (`model(x, adj)` in training mode: a
     rowgrad.RowSelectable), its gradient travels in STRUCTURAL form (NLLGrad: the label vector and
@@ -72,7 +83,7 @@ def nll_loss(log_probs, target):
     from pygcn_amd.rowgrad import RowSelectable
     structural = (isinstance(log_probs, RowSelectable) and log_probs.dim() == 2 and log_probs.is_cuda
                   and log_probs.requires_grad and target.dtype == torch.int64
-                  and target.device == log_probs.device)
-    if isinstance(log_probs, RowSelectable):
+                  and target.device == log_probs.device and ignore_index < 0)
+    if isinstance(log_probs, torch.Tensor) and type(log_probs) is not torch.Tensor:
         log_probs = log_probs.as_subclass(torch.Tensor)
-    return _NLLMean.apply(log_probs, target.contiguous(), structural)
+    return _NLLMean.apply(log_probs, target.contiguous(), structural, int(ignore_index))

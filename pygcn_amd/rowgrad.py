@@ -62,6 +62,30 @@ class SelectRowsFunction(torch.autograd.Function):
         return RowGrad(ctx.idx, grad_rows, ctx.n), None
 
 
+class LossRows(torch.Tensor):
+    """`output[idx_train]` of the model's RowSelectable output: an ordinary tensor, except that
+    upstream's very next call — `F.nll_loss(output[idx_train], labels[idx_train])`
+    (pygcn/train.py:153) with its default arguments — runs as the gather / scatter pair of
+    pygcn_amd.functional.nll_loss instead of torch's one-thread-per-row kernels (2 ms of a 50 ms
+    epoch at C4, 10 ms of 106 at C5).  Same value, same gradient, `ignore_index` honoured; any other
+    use of the tensor is the plain one."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if (func is torch.nn.functional.nll_loss and len(args) >= 2 and isinstance(args[0], LossRows)
+                and len(args) == 2 and args[0].dim() == 2 and isinstance(args[1], torch.Tensor)
+                and args[1].dim() == 1 and args[1].dtype == torch.int64
+                and kwargs.get("weight") is None and kwargs.get("size_average") is None
+                and kwargs.get("reduce") is None and kwargs.get("reduction", "mean") == "mean"
+                and set(kwargs) <= {"weight", "size_average", "reduce", "reduction", "ignore_index"}):
+            from pygcn_amd.functional import nll_loss
+            return nll_loss(args[0].as_subclass(torch.Tensor), args[1], kwargs.get("ignore_index", -100))
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return pytree.tree_map(lambda o: o.as_subclass(torch.Tensor) if isinstance(o, LossRows) else o, out)
+
+
 class RowSelectable(torch.Tensor):
     """Marker subclass of the model's output (see the module docstring)."""
 
@@ -73,7 +97,7 @@ class RowSelectable(torch.Tensor):
                 and args[1].dim() == 1 and args[1].dtype == torch.int64 and args[0].dim() == 2
                 and args[0].requires_grad and torch.is_grad_enabled()
                 and args[1].device == args[0].device):
-            return SelectRowsFunction.apply(args[0].as_subclass(torch.Tensor), args[1])
+            return SelectRowsFunction.apply(args[0].as_subclass(torch.Tensor), args[1]).as_subclass(LossRows)
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         # results are ordinary tensors: only the model's own output is selectable

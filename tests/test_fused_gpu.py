@@ -429,3 +429,48 @@ def test_row_sets_of_aliasing_index_views_do_not_collide(oracle, dev):
         for k, v in grads.items():
             mod, name = k.split(".")
             assert_normwise(getattr(getattr(model, mod), name).grad.cpu(), v, 2e-5, f"aliasing views: {k}")
+
+
+def test_upstream_loss_lines_with_ignore_index_and_bf16(oracle, dev):
+    """`F.nll_loss(output[idx_train], labels[idx_train])` on the model's output runs as the gather /
+    scatter pair (rowgrad.LossRows) and the all-vertices loss as the structural NLLGrad — both must
+    honour torch's `ignore_index` (labels of -100 add nothing and do not count), at fp32 against
+    torch's own kernels on a plain tensor."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.functional import nll_loss
+    from pygcn_amd.rowgrad import LossRows
+    from pygcn_amd.utils import rmat_graph
+    n, F_ = 20000, 64
+    rowptr, col, val = rmat_graph(n, 200000, seed=61, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    x = torch.randn(n, F_, device=dev)
+    labels = torch.randint(0, F_, (n,), device=dev)
+    labels[::7] = -100
+    idx = torch.randperm(n, device=dev)[: n // 4]
+    torch.manual_seed(2)
+    model = GCN(F_, F_, F_, dropout=0.0).to(dev)
+    model.train()
+    results = []
+    for route in ("intercepted", "plain"):
+        model.zero_grad(set_to_none=True)
+        out = model(x, g)
+        if route == "plain":
+            out = out.as_subclass(torch.Tensor)
+        sel = out[idx]
+        assert isinstance(sel, LossRows) == (route == "intercepted")
+        loss = torch.nn.functional.nll_loss(sel, labels[idx])
+        loss.backward()
+        results.append((loss.item(), [p.grad.clone() for p in model.parameters()]))
+    assert abs(results[0][0] - results[1][0]) <= 1e-6 * abs(results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert_normwise(a.cpu(), b.cpu().numpy(), 5e-5, "LossRows route vs torch's nll_loss")
+    # all vertices, structural gradient with ignored rows vs torch's dense gradient
+    results = []
+    for fn in (nll_loss, torch.nn.functional.nll_loss):
+        model.zero_grad(set_to_none=True)
+        loss = fn(model(x, g), labels)
+        loss.backward()
+        results.append((loss.item(), [p.grad.clone() for p in model.parameters()]))
+    assert abs(results[0][0] - results[1][0]) <= 1e-6 * abs(results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert_normwise(a.cpu(), b.cpu().numpy(), 5e-5, "NLLGrad with ignored rows vs torch")

@@ -338,7 +338,10 @@ def test_row_sparse_gradient_carrier_mechanics():
     out = Layer.apply(Layer.apply(x, w1), w2).as_subclass(RowSelectable)
     assert type(out[idx.tolist()]) is torch.Tensor and out[idx.tolist()].grad_fn.name() != "SelectRowsFunctionBackward"
     assert type(out[2:5]) is torch.Tensor and type(out + 1) is torch.Tensor and type(out.detach()) is torch.Tensor
-    assert out[idx].grad_fn.name() == "SelectRowsFunctionBackward"
+    from pygcn_amd.rowgrad import LossRows
+    sel = out[idx]             # (a LossRows alias of the selection: upstream's next call is F.nll_loss)
+    assert isinstance(sel, LossRows) and type(sel + 1) is torch.Tensor
+    assert "SelectRowsFunctionBackward" in (sel.grad_fn.name(), sel.grad_fn.next_functions[0][0].name())
     with torch.no_grad():
         assert out.detach().as_subclass(RowSelectable)[idx].grad_fn is None
     rg = RowGrad(torch.tensor([2, 0, 2]), torch.ones(3, 2), 4)
