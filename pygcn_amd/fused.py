@@ -346,6 +346,8 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
     gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
     w2t = w2.t().contiguous()
     gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_scale=ctx.scale) if fast else None
+    if gpre1 is None and dt == torch.bfloat16:       # (C5: the bf16 GEMM carries the mask in its store too)
+        gpre1 = _spmm.gemm_bf16(grad_sup2, w2t, mask_src=h1, mask_scale=ctx.scale)
     if gpre1 is None:
         gh1 = _dense_forward(grad_sup2, w2t, gs_bound, gh_max)
         gpre1 = _spmm.relu_dropout_backward(gh1.contiguous(), h1, ctx.scale)
