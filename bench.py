@@ -331,7 +331,9 @@ def main():
         install_host_staging()
     elif world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        # (a mismatched or lost collective must end the run, not hang it until the driver's clock does)
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=8))
 
     if args.fail_rank == rank:       # (tests/test_bench_launch.py: a rank that dies after the rendezvous)
         os._exit(3)

@@ -65,3 +65,27 @@ def test_bench_launcher_reports_a_dead_rank():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert dt < 500
+
+
+@pytest.mark.gpu
+def test_bench_dense_loss_mode_and_measured_fields():
+    """`bench.py --dense-loss` (the loss over all vertices as the timed epoch) and the fields the
+    line must carry: measured host synchronisations, the full-height transpose product as a
+    GEdge/s + roofline pair, the GEMM scheme, the cross-world-size loss check."""
+    r, _ = _run(["--config", "tiny", "--dense-loss", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                 "--no-extras"], 600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["mode"] == "train-epoch (loss over all vertices)"
+    assert line["host_syncs_per_step"] == 0
+    assert line["spmm_bwd_dense_gedges"] > 0 and 0 < line["spmm_bwd_dense_roofline_frac"] < 1.2
+    assert line["gemm_scheme"].startswith("h2") and line["loss_check"]["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and line["unit"] == "GEdge/s"
+    r2, _ = _run(["--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], 600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    full = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("ms_per_step_dense_loss", "host_syncs_per_step_dense_loss", "ms_per_step_reference_call",
+                "host_syncs_per_step_reference_call", "ms_per_step_exact_gemm", "spmm_bwd_dense_gedges"):
+        assert key in full, key
+    assert full["host_syncs_per_step"] == 0 and full["host_syncs_per_step_dense_loss"] == 0
+    assert full["host_syncs_per_step_reference_call"] == 0
