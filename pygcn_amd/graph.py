@@ -106,7 +106,10 @@ class CSRGraph:
         (row, col), duplicates reduced in storage order: deterministic, no atomics).
         `reduce="max"` keeps the largest of duplicate entries instead of their sum (the
         reference's symmetrization, see from_edge_list).  `coalesced` is accepted for
-        compatibility; sorted unique input simply sorts to itself."""
+        compatibility; sorted unique input simply sorts to itself.
+        Limits: HIP tensors only (no host path), and fewer than 2³² − 1 triplets per call (the
+        sort carries 32-bit storage positions) — both raise a RuntimeError here, before any launch.
+        Larger inputs: convert in row ranges, or hand CSR arrays to the constructor."""
         row = torch.as_tensor(row)
         device = torch.device(device) if device is not None else row.device
         row = row.to(device=device, dtype=torch.int64).contiguous()
@@ -117,6 +120,9 @@ class CSRGraph:
         nnz = int(row.numel())
         if col.numel() != nnz or val.numel() != nnz:
             raise RuntimeError("COO row / col / val must have the same length")
+        if nnz >= 2 ** 32 - 1:
+            raise RuntimeError(f"from_coo: {nnz} triplets; the device COO->CSR conversion takes fewer than "
+                               "2^32 - 1 per call (convert in row ranges, or pass CSR arrays)")
         if nnz and (int(row.max()) >= n_rows or int(col.max()) >= n_cols or
                     int(row.min()) < 0 or int(col.min()) < 0):
             raise RuntimeError("COO index out of range for the given shape")
@@ -149,9 +155,14 @@ class CSRGraph:
             adj = coo_matrix(ones, (src, dst))                  duplicates SUMMED        :360-362
             adj = adj + adj.T*(adj.T > adj) - adj*(adj.T > adj)  = max(adj, adj.T)       :365
             adj = normalize(adj + I)                            D^-1 (A + I)            :368
-        Every step is the native COO->CSR reduction (sum / max) or the native row normalisation."""
+        Every step is the native COO->CSR reduction (sum / max) or the native row normalisation.
+        Symmetrizing doubles the triplet count of the intermediate conversion: with `symmetrize` the
+        input may hold fewer than 2³¹ pairs (from_coo's 2³² − 1 limit), checked before any launch."""
         dev = torch.device(device)
         e = torch.as_tensor(edges).to(device=dev, dtype=torch.int64)
+        if symmetrize and 2 * e.shape[0] + (n if self_loops else 0) >= 2 ** 32 - 1:
+            raise RuntimeError(f"from_edge_list: {e.shape[0]} pairs; symmetrization doubles them past the "
+                               "2^32 - 1 triplets one device conversion takes")
         g = cls.from_coo(e[:, 0], e[:, 1], torch.ones(e.shape[0], device=dev), (n, n), **kw)
         if symmetrize:
             r, c, v = g.coo()
