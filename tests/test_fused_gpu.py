@@ -474,3 +474,54 @@ def test_upstream_loss_lines_with_ignore_index_and_bf16(oracle, dev):
     assert abs(results[0][0] - results[1][0]) <= 1e-6 * abs(results[1][0])
     for a, b in zip(results[0][1], results[1][1]):
         assert_normwise(a.cpu(), b.cpu().numpy(), 5e-5, "NLLGrad with ignored rows vs torch")
+
+
+def test_hooks_and_a_second_backward_see_ordinary_gradients(oracle, dev):
+    """the model's output is a Tensor subclass in training mode and its
+    gradient may travel as a storage-less wrapper (RowGrad / NLLGrad).  Whoever else touches that
+    gradient must see the ordinary dense tensor: a hook registered on the output (it can compute
+    with it and even replace it), `retain_graph=True` followed by a second backward, and
+    `torch.autograd.grad` with respect to the output."""
+    from pygcn_amd import GCN, CSRGraph
+    from pygcn_amd.functional import nll_loss
+    from pygcn_amd.utils import rmat_graph
+    n, F_ = 20000, 64
+    rowptr, col, val = rmat_graph(n, 200000, seed=71, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    x = torch.randn(n, F_, device=dev)
+    labels = torch.randint(0, F_, (n,), device=dev)
+    idx = torch.randperm(n, device=dev)[: n // 10]
+    torch.manual_seed(4)
+    model = GCN(F_, F_, F_, dropout=0.0).to(dev)
+    model.train()
+
+    def grads(loss_of, hook=None, twice=False):
+        model.zero_grad(set_to_none=True)
+        out = model(x, g)
+        if hook is not None:
+            out.register_hook(hook)
+        loss = loss_of(out)
+        loss.backward(retain_graph=twice)
+        if twice:
+            loss.backward()
+        return [p.grad.clone() for p in model.parameters()]
+    for loss_of in (lambda o: torch.nn.functional.nll_loss(o[idx], labels[idx]), lambda o: nll_loss(o, labels)):
+        base = grads(loss_of)
+        seen = []
+
+        def hook(gr):
+            seen.append((tuple(gr.shape), float(gr.abs().sum())))       # computing with it materialises it
+            return gr * 2.0                                              # ... and so does replacing it
+        doubled = grads(loss_of, hook=hook)
+        assert seen and seen[0][0] == (n, F_) and seen[0][1] > 0
+        for a, b in zip(doubled, base):
+            assert_normwise(a.cpu(), 2.0 * b.cpu().numpy(), 5e-5, "hook that doubles the gradient")
+        two = grads(loss_of, twice=True)                                 # gradients accumulate over two passes
+        for a, b in zip(two, base):
+            assert_normwise(a.cpu(), 2.0 * b.cpu().numpy(), 5e-5, "retain_graph + second backward")
+        model.zero_grad(set_to_none=True)
+        out = model(x, g)
+        (g_out,) = torch.autograd.grad(loss_of(out), out, retain_graph=True)
+        dense = g_out + 0                                                # any operator sees the dense tensor
+        assert type(dense) is torch.Tensor and dense.shape == (n, F_) and torch.isfinite(dense).all()
+        assert int((dense != 0).any(1).sum()) in (idx.numel(), n)
