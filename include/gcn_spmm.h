@@ -216,6 +216,12 @@ typedef struct gcn_epilogue {
     /* Added to the row index in the dropout counter (ABI 22): a row-block shard passes the global
      * index of its first row, so the masks of a sharded run are those of the single-GPU run. */
     int64_t drop_row_base;
+    /* Optional OUTPUT (NULL = none; ABI 22): one DEVICE float, zeroed by the caller, that receives
+     * max |stored value| of the launch (atomic max of the bit patterns: inf / NaN patterns sort
+     * above every finite value, so an overflow is never lost) — the bound the scaled GEMMs that
+     * consume this product need (gcn_gemm_xw256_f32_h2: x_absmax_bound), without a reduction pass
+     * over the result.  One atomic per wavefront at most. */
+    float *c_absmax;
 } gcn_epilogue;
 
 /* gcn_spmm_csr with the full epilogue (ep may be NULL: plain product). */

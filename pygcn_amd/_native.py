@@ -44,7 +44,8 @@ class GcnEpilogue(ctypes.Structure):
                 ("b2", ctypes.c_void_p), ("ldb2", ctypes.c_int64), ("b_split", ctypes.c_int64),
                 ("c_row_nonzero", ctypes.c_void_p), ("log_softmax", ctypes.c_int32),
                 ("seed_dev", ctypes.c_void_p), ("c_row_select", ctypes.c_void_p),
-                ("c_skip_zero_rows", ctypes.c_int32), ("drop_row_base", ctypes.c_int64)]
+                ("c_skip_zero_rows", ctypes.c_int32), ("drop_row_base", ctypes.c_int64),
+                ("c_absmax", ctypes.c_void_p)]
 
 
 class GcnGemmEpilogue(ctypes.Structure):

@@ -100,6 +100,7 @@ struct KParams {
     const uint64_t *seed_dev;   // optional device-resident dropout seed (overrides seed_lo/hi)
     const uint32_t *csel;       // optional bitmap over output rows: clear bit = row not wanted
     int32_t cskip;              // with cflag: all-zero rows are not stored
+    uint32_t *cabsmax;          // optional output: max |stored value| as BITS (atomic max; inf / NaN sort on top)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -294,9 +295,11 @@ __device__ __forceinline__ float group_sum(float s)
 // layer of every forward pass: without the row-flag code the bf16 narrow instantiation keeps 6
 // waves per SIMD), 2 keeps both: the plain instantiations keep
 // the register budget they were tuned with (wide fp32: 62 VGPRs; the extras cost 8-15 more)
+// Returns (XEPI >= 2 with p.cabsmax set, else 0) the largest |stored value| of this lane as its bit
+// pattern: callers keep a running maximum per lane and publish it once per wave (publish_absmax).
 template <typename T, int VEC, int LPR, int XEPI, bool ALLOW_SKIP = true>
-__device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, bool act,
-                                          const float (&acc)[VEC], const float (&bias)[VEC])
+__device__ __forceinline__ uint32_t store_out(const KParams &p, int64_t row, int f, bool act,
+                                              const float (&acc)[VEC], const float (&bias)[VEC])
 {
     float o[VEC];
 #pragma unroll
@@ -339,6 +342,27 @@ __device__ __forceinline__ void store_out(const KParams &p, int64_t row, int f, 
         T *dst = (T *)p.C + row * p.ldc + f;
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
     }
+    uint32_t amax = 0u;
+    if (XEPI >= 2 && p.cabsmax != nullptr && do_store) {   // (uniform pointer test)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            if (f + i < p.F) amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
+    }
+    return amax;
+}
+
+// One atomic per wave at most, and only when the wave's maximum beats the value already published
+// (a plain load at the end of the wave's work: its latency hides nothing that matters).
+template <int XEPI>
+__device__ __forceinline__ void publish_absmax(const KParams &p, uint32_t amax)
+{
+    if (XEPI >= 2 && p.cabsmax != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, off, kWave));
+        if ((threadIdx.x & (kWave - 1)) == 0 && amax != 0u &&
+            amax > __atomic_load_n(p.cabsmax, __ATOMIC_RELAXED))
+            atomicMax(p.cabsmax, amax);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,7 +387,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
                                             const float *__restrict__ valp, int ne, int lane,
                                             unsigned ld_off_bytes, float (&acc)[VEC],
                                             int rel_end, int nr, int64_t row0, int f, bool act,
-                                            const float (&bias)[VEC])
+                                            const float (&bias)[VEC], uint32_t &amax)
 {
     typedef typename Elem<T, VEC>::Raw Raw;
     static_assert(sizeof(Raw) == 16, "wide kernel moves 16 bytes per lane");
@@ -385,7 +409,7 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
     const int want = (sel && lane < nr) ? (int)row_bit(p.csel, (int)row0 + lane) : 1;
     auto emit = [&](int rr) {   // store row rr of the item unless the caller does not want it
         if (!sel || readlane_i(want, rr))
-            store_out<T, VEC, kWave, XEPI>(p, row0 + rr, f, act, acc, bias);
+            amax = max(amax, store_out<T, VEC, kWave, XEPI>(p, row0 + rr, f, act, acc, bias));
     };
     auto consume = [&](int e, const u32x4 &raw, float a) {
         if (ROWS) {
@@ -503,8 +527,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
         if (FLAGS && p.csel != nullptr && !row_bit(p.csel, row)) return;   // long row not wanted
         const int64_t e0 = p.chunk_e0[item];
         const int64_t e1 = min(e0 + (int64_t)p.long_thresh, (int64_t)rp[row + 1]);
+        uint32_t unused = 0u;
         wide_stream<T, VEC, D, false, FLAGS, XEPI>(p, p.col + e0, p.val + e0, (int)(e1 - e0), lane,
-                                      ld_off_bytes, acc, 0, 0, 0, f, act, bias);
+                                      ld_off_bytes, acc, 0, 0, 0, f, act, bias, unused);
         if (act) {
             float *dst = p.partial + (int64_t)item * p.F + f;
 #pragma unroll
@@ -524,8 +549,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_wide_kernel(KParam
 #pragma unroll
         for (int i = 0; i < VEC; ++i) bias[i] = p.bias[f + i];
     }
+    uint32_t amax = 0u;
     wide_stream<T, VEC, D, true, FLAGS, XEPI>(p, p.col + ea, p.val + ea, ne, lane, ld_off_bytes, acc, rel_end,
-                                 nr, (int64_t)ra, f, act, bias);
+                                 nr, (int64_t)ra, f, act, bias, amax);
+    publish_absmax<XEPI>(p, amax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -656,6 +683,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
     }
 
     const bool sel = p.csel != nullptr;   // output-row selection (wave-uniform)
+    uint32_t amax = 0u;                   // running max |stored value| of this lane (see store_out)
     if (item < p.n_chunks) {
         const int row = p.chunk_row[item];
         if (sel && !row_bit(p.csel, row)) return;   // long row not wanted
@@ -694,9 +722,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
             narrow_row<T, VEC, LPR, U>(p, p.col, p.val, e0, e1, g, ld_off, acc, flags);
-            store_out<T, VEC, LPR, XEPI>(p, (int64_t)r, f, act && g == 0, acc, bias);
+            amax = max(amax, store_out<T, VEC, LPR, XEPI>(p, (int64_t)r, f, act && g == 0, acc, bias));
             e0 = e1;
         }
+        publish_absmax<XEPI>(p, amax);
         return;
     }
 
@@ -784,7 +813,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int ru = 0; ru < RU; ++ru) {
             if (row[ru] >= 0)
-                store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias);
+                amax = max(amax, store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + row[ru]), f, act, a2[ru], bias));
         }
     }
 
@@ -797,8 +826,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         narrow_row<T, VEC, LPR, U>(p, p.col, p.val, ea + s0, ea + s1, g, ld_off, acc, flags);
-        store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias);
+        amax = max(amax, store_out<T, VEC, LPR, XEPI>(p, (int64_t)(ra + rr), f, act && g == 0, acc, bias));
     }
+    publish_absmax<XEPI>(p, amax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -812,6 +842,7 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
     const int64_t row = p.long_row[j];
     if (p.csel != nullptr && !row_bit(p.csel, (int)row)) return;   // (its chunks were skipped too)
     const int c0 = p.long_chunk0[j], c1 = p.long_chunk0[j + 1];
+    uint32_t amax = 0u;
     if (p.log_softmax) {
         // F <= 512 (host check): thread t owns columns t and t + 256; block-wide max and sum
         __shared__ float red[2][4];
@@ -848,8 +879,10 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
                 const float o[1] = {z[k] - lse};
                 ((T *)p.C)[row * p.ldc + f] = Elem<T, 1>::pack(o);
                 if (p.cflag != nullptr && o[0] != 0.f) p.cflag[row] = 1;
+                amax = max(amax, __float_as_uint(o[0]) & 0x7fffffffu);
             }
         }
+        publish_absmax<2>(p, amax);
         return;
     }
     for (int f = threadIdx.x; f < p.F; f += blockDim.x) {
@@ -857,8 +890,9 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
         for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
-        store_out<T, 1, 1, 2, false>(p, row, f, true, a, b);   // long rows: always stored
+        amax = max(amax, store_out<T, 1, 1, 2, false>(p, row, f, true, a, b));   // long rows: always stored
     }
+    publish_absmax<2>(p, amax);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,7 +1108,7 @@ template <typename T, int VEC, int LPR>
 void launch_narrow(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
     const dim3 block(kWave * kWavesPerBlock);
-    const int xepi = kp.cflag != nullptr ? 2 : (kp.log_softmax ? 1 : 0);   // instantiation with the extras
+    const int xepi = (kp.cflag != nullptr || kp.cabsmax != nullptr) ? 2 : (kp.log_softmax ? 1 : 0);   // extras
 #define GCN_LAUNCH_NARROW(I, X) \
     hipLaunchKernelGGL((spmm_narrow_kernel<T, VEC, LPR, I, X>), grid, block, 0, s, kp)
     if (xepi == 2) {
@@ -1109,7 +1143,7 @@ void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
 {
     constexpr int D = 8;
     const dim3 block(kWave * kWavesPerBlock);
-    const bool xepi = kp.log_softmax || kp.cflag != nullptr;
+    const bool xepi = kp.log_softmax || kp.cflag != nullptr || kp.cabsmax != nullptr;
 #define GCN_LAUNCH_WIDE(I, FL, X) \
     hipLaunchKernelGGL((spmm_wide_kernel<T, VEC, I, D, FL, X>), grid, block, 0, s, kp)
     if (kp.bflag != nullptr || kp.csel != nullptr) {   // operand hint / row selection: the flag variant
@@ -1364,6 +1398,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;
     kp.seed_dev = ep ? ep->seed_dev : nullptr;
     kp.csel = ep ? ep->c_row_select : nullptr;
+    kp.cabsmax = ep ? (uint32_t *)ep->c_absmax : nullptr;
     kp.cskip = (ep && ep->c_skip_zero_rows && ep->c_row_nonzero) ? 1 : 0;
     kp.B2 = ep ? ep->b2 : nullptr;
     kp.ldb2 = ep && ep->b2 ? ep->ldb2 : 0;

@@ -222,11 +222,13 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     # ---- layer 2: Âᵀ · grad_pre2 — only rows R of grad_pre2 are non-zero and only rows R2 of
     # the result can be: the product runs on that block of Âᵀ (RowSets.at_block), compact
     # operand [|R|, C] in, compact result [|R2|, C] out; nothing of size [N, C] exists
-    grad_sup2 = spmm_csr(rs.at_block, gp.contiguous(), tag="bwd_l2")
     f32 = dt == torch.float32
-    # bound of max|grad_sup2| for the scaled GEMMs: its exact maximum — the tensor is compact
-    # ([|R2|, C]: 0.4 ms at C4), where ‖Âᵀ‖∞·max|grad_pre2| overshoots by the hub column sums
-    gs_bound = _exact_absmax(grad_sup2) * 1.0001 if f32 else None
+    # bound of max|grad_sup2| for the scaled GEMMs: its EXACT maximum, reported by the product
+    # itself (gcn_epilogue.c_absmax: one conditional atomic per wave) — ‖Âᵀ‖∞·max|grad_pre2| would
+    # overshoot by the hub column sums, a separate reduction pass costs 0.5 ms at C4
+    gs_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
+    grad_sup2 = spmm_csr(rs.at_block, gp.contiguous(), tag="bwd_l2", c_absmax=gs_max)
+    gs_bound = gs_max * 1.0001 if f32 else None
     # h1 is read at the rows R2 in place (row lists), no compacting copy; the ReLU / dropout
     # mask (h1 > 0 encodes ReLU and keep) is applied in the GEMM's store
     fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
@@ -332,11 +334,13 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
     grad_w1 = grad_w2 = grad_b1 = grad_x = None
     if not (need_x or need_w1 or need_b1 or need_w2):
         return grad_x, grad_w1, grad_b1, grad_w2, grad_b2
-    grad_sup2 = spmm_csr(graph_t, gp.contiguous(), tag="bwd_l2")
+    # exact max|grad_sup2| from the product itself (gcn_epilogue.c_absmax); the analytic
+    # ‖Âᵀ‖∞·max|g| is loose by the hub column sums and would cost the scaled GEMMs their low-order
+    # bits, a separate reduction over [10⁷, 256] costs 2 ms
+    gs_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
+    grad_sup2 = spmm_csr(graph_t, gp.contiguous(), tag="bwd_l2", c_absmax=gs_max)
     del gp
-    # exact maximum by one reduction pass (1.4 ms at [10⁷, 256]); the analytic ‖Âᵀ‖∞·max|g| is
-    # loose by the hub column sums and would cost the scaled GEMMs their low-order bits
-    gs_bound = _exact_absmax(grad_sup2) * 1.0001 if f32 else None
+    gs_bound = gs_max * 1.0001 if f32 else None
     fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
     if need_w2:
         grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, None, None, ctx.h_bound, gs_bound) \

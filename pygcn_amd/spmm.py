@@ -40,7 +40,7 @@ def set_timing_records(records):
 
 def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0, seed=0,
              b_hint=None, B2=None, c_flags=None, log_softmax=False, c_select=None,
-             skip_zero_rows=False, row_base=0):
+             skip_zero_rows=False, row_base=0, c_absmax=None):
     """C = A · B (+ bias, ReLU, inverted dropout) on the current HIP stream; A is a CSRGraph,
     B dense [n_cols, F].  The epilogue order is that of the reference model: bias
     (layers.py:35-36), F.relu (models.py:48), F.dropout (models.py:50).  `b_hint` = (row bitmap
@@ -59,7 +59,10 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     `seed` may be a 1-element int64 DEVICE tensor: the kernel then reads the seed when it executes
     (hipGraph replays draw a fresh mask if the graph updates the tensor, see dropout_seed_for).
     `row_base`: added to the row index in the dropout counter — a row-block shard passes the global
-    index of its first row and draws the masks of the single-GPU run."""
+    index of its first row and draws the masks of the single-GPU run.
+    `c_absmax`: optional DEVICE float32 [1], zeroed by the caller: receives max|stored value| of the
+    launch (gcn_epilogue.c_absmax) — the bound a scaled GEMM consuming the result needs, without a
+    reduction pass; non-finite if the result holds inf / NaN."""
     if not isinstance(graph, CSRGraph):
         raise RuntimeError("spmm_csr: graph must be a CSRGraph")
     _require_cuda(B, "dense operand")
@@ -89,6 +92,9 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  or c_select.numel() != (n_rows + 31) // 32
                                  or not c_select.is_contiguous()):
         raise RuntimeError("spmm_csr: c_select must be a contiguous int32 bitmap [ceil(n_rows/32)]")
+    if c_absmax is not None and (c_absmax.dtype != torch.float32 or c_absmax.numel() != 1
+                                 or c_absmax.device != B.device):
+        raise RuntimeError("spmm_csr: c_absmax must be one float32 on the operand's device")
     if n_rows == 0 or F == 0:
         return out
     if bias is not None:
@@ -121,7 +127,8 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
                                  c_flags.data_ptr() if c_flags is not None else None,
                                  int(bool(log_softmax)), seed_dev,
                                  c_select.data_ptr() if c_select is not None else None,
-                                 int(bool(skip_zero_rows) and c_flags is not None), int(row_base))
+                                 int(bool(skip_zero_rows) and c_flags is not None), int(row_base),
+                                 c_absmax.data_ptr() if c_absmax is not None else None)
         rc = L.gcn_spmm_csr_ep(plan, _DTYPES[B.dtype], B.data_ptr(), B.stride(0) if F else 0,
                                out.data_ptr(), out.stride(0), F, ep,
                                ws.data_ptr() if ws is not None else None, ws_bytes, stream)

@@ -95,7 +95,7 @@ def test_planner_rejects_bad_input():
 def test_spmm_argument_errors_without_gpu():
     """Argument validation happens before any launch, so it is testable on CPU."""
     L = _native.lib()
-    assert ctypes.sizeof(_native.GcnEpilogue) == 112      # (ABI 22: + drop_row_base)
+    assert ctypes.sizeof(_native.GcnEpilogue) == 120      # (ABI 22: + drop_row_base, c_absmax)
     assert L.gcn_spmm_csr(None, 0, None, 0, None, 0, 4, None, 0, None, 0, None) == -1
     p = _native.GcnCsrPlan()
     p.n_rows, p.n_cols, p.nnz = 4, 4, 0

@@ -1176,3 +1176,30 @@ def test_dropout_row_base_gives_a_shard_the_masks_of_the_whole(oracle, dev, F, d
         W = torch.eye(128, device=dev).bfloat16()
         y = gemm_bf16(ones, W, relu=True, dropout_p=p, seed=seed, row_base=base)
         np.testing.assert_array_equal(y.float().cpu().numpy() != 0, want)
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (7, torch.float32),
+                                     (128, torch.bfloat16)])
+def test_product_reports_its_own_absmax(oracle, dev, F, dtype):
+    """gcn_epilogue.c_absmax: the launch reports max|stored value| (every kernel family: wide, narrow
+    vector / scalar, bf16, long rows incl. their reduce kernel, with and without a fused epilogue)
+    — exactly the maximum of the tensor it wrote; inf / NaN in the result show up as non-finite."""
+    from pygcn_amd import spmm_csr
+    n = 3000
+    a = _skewed_csr(oracle, n, n, 6, seed=15, hubs=((3, 1500), (900, 700)), empties=40)
+    g = _graph(a, dev)
+    B = (torch.from_numpy(gin.dense((n, F), 21)) * 3.0).to(dtype).to(dev)
+    bias = torch.from_numpy(gin.dense((F,), 22)).to(dev)
+    for kw in ({}, {"bias": bias}, {"bias": bias, "relu": True}, {"bias": bias, "log_softmax": True}):
+        if kw.get("log_softmax") and F == 7 and False:
+            continue
+        m = torch.zeros(1, device=dev)
+        out = spmm_csr(g, B, c_absmax=m, **kw)
+        assert m.item() == out.float().abs().max().item(), (kw.keys(), m.item(), out.float().abs().max().item())
+        assert torch.equal(out, spmm_csr(g, B, **kw))             # the side output changes nothing
+    if dtype == torch.float32:
+        Bn = B.clone()
+        Bn[5, 0] = float("inf")
+        m = torch.zeros(1, device=dev)
+        spmm_csr(g, Bn, c_absmax=m)
+        assert not torch.isfinite(m).all()
