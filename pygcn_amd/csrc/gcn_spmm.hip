@@ -344,9 +344,11 @@ __device__ __forceinline__ uint32_t store_out(const KParams &p, int64_t row, int
     }
     uint32_t amax = 0u;
     if (XEPI >= 2 && p.cabsmax != nullptr && do_store) {   // (uniform pointer test)
+        float st[VEC];                                       // the values as STORED (bf16: rounded)
+        Elem<T, VEC>::unpack(Elem<T, VEC>::pack(o), st);
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
-            if (f + i < p.F) amax = max(amax, __float_as_uint(o[i]) & 0x7fffffffu);
+            if (f + i < p.F) amax = max(amax, __float_as_uint(st[i]) & 0x7fffffffu);
     }
     return amax;
 }
@@ -879,7 +881,9 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
                 const float o[1] = {z[k] - lse};
                 ((T *)p.C)[row * p.ldc + f] = Elem<T, 1>::pack(o);
                 if (p.cflag != nullptr && o[0] != 0.f) p.cflag[row] = 1;
-                amax = max(amax, __float_as_uint(o[0]) & 0x7fffffffu);
+                float st[1];
+                Elem<T, 1>::unpack(Elem<T, 1>::pack(o), st);
+                amax = max(amax, __float_as_uint(st[0]) & 0x7fffffffu);
             }
         }
         publish_absmax<2>(p, amax);
@@ -1422,21 +1426,9 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
                  int64_t ldc, int64_t F, const float *bias, int relu, void *workspace,
                  size_t workspace_bytes, void *stream)
 {
-    gcn_epilogue ep;
+    gcn_epilogue ep = {};          // (every option off; fields added later stay zero)
     ep.bias = bias;
     ep.relu = relu;
-    ep.dropout_p = 0.f;
-    ep.seed = 0;
-    ep.b_row_nonzero = nullptr;
-    ep.b_nnz_rows = nullptr;
-    ep.c_row_nonzero = nullptr;
-    ep.log_softmax = 0;
-    ep.seed_dev = nullptr;
-    ep.c_row_select = nullptr;
-    ep.c_skip_zero_rows = 0;
-    ep.b2 = nullptr;
-    ep.ldb2 = 0;
-    ep.b_split = 0;
     return gcn_spmm_csr_ep(plan, dtype, B, ldb, C, ldc, F, &ep, workspace, workspace_bytes, stream);
 }
 
