@@ -164,17 +164,23 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
         halo, pending = rs.hx.exchange_begin(gp)
         rs.hx.exchange_end(pending)
         sg.last_recv_bytes["bwd"] = rs.hx.last_recv_bytes
+        f32 = dt == torch.float32
+        # max|grad_sup2| — the bound of the scaled GEMMs below — comes out of the product itself
+        # (gcn_epilogue.c_absmax; test stand-ins of the product take a reduction pass instead)
+        gs_max = torch.zeros(1, dtype=torch.float32, device=dev) if (f32 and sg._hinted_product) else None
+        kw = {"c_absmax": gs_max} if gs_max is not None else {}
         if rs.n_u:
-            grad_sup2 = sg._spmm(rs.at_block, gp, tag="bwd_local", B2=halo)
+            grad_sup2 = sg._spmm(rs.at_block, gp, tag="bwd_local", B2=halo, **kw)
         elif halo.shape[0]:                       # no labelled vertex of my own: halo rows only
-            grad_sup2 = sg._spmm(rs.at_block, halo, tag="bwd_local")
+            grad_sup2 = sg._spmm(rs.at_block, halo, tag="bwd_local", **kw)
         else:
             grad_sup2 = gp.new_zeros((rs.n2, gp.shape[1]))
         sg._toc(ev, "bwd")
-        f32 = dt == torch.float32
-        # bound of max|grad_sup2| for the scaled GEMMs: its exact maximum (a compact [|R2_r|, C] tensor)
-        gs_bound = (torch.linalg.vector_norm(grad_sup2, ord=float("inf")).float().reshape(1) * 1.0001
-                    if rs.n2 else grad_sup2.new_zeros(1).float()) if f32 else None
+        gs_bound = None
+        if f32:
+            gs_bound = gs_max * 1.0001 if gs_max is not None else (
+                torch.linalg.vector_norm(grad_sup2, ord=float("inf")).float().reshape(1) * 1.0001
+                if rs.n2 else grad_sup2.new_zeros(1).float())
         fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256 \
             and rs.n2 > 0
         grad_w1 = grad_w2 = grad_b1 = None
