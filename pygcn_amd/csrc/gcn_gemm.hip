@@ -754,6 +754,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
                 uint32_t r4[4] = {0u, 0u, 0u, 0u};     // the 8 keep fields of a pair of column groups
+                // backward mask: the four 16-byte pieces of this column block are fetched TOGETHER,
+                // ahead of the stores — loads and stores share one counter on gfx9 and may complete
+                // out of order, so a load issued after a store is waited for with vmcnt(0): one
+                // drain per column block instead of one per store
+                f32x4 mk[4];
+                if (!FWD_EPI && mrow != nullptr) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mk[g] = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v = {acc[nb][4 * g] * back_a, acc[nb][4 * g + 1] * back_a,
@@ -800,8 +809,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                         v.z = (w1 & 0xFFFFu) >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
                         v.w = (w1 >> 16) >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
                     }
-                    if (mrow != nullptr) {
-                        const f32x4 m = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
+                    if (!FWD_EPI && mrow != nullptr) {
+                        const f32x4 m = mk[g];
                         v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
                         v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
                         v.z = m.z > 0.f ? v.z * mask_scale : 0.f;

@@ -431,3 +431,33 @@ def test_bf16_gemm_with_backward_mask_in_the_store(dev):
     want2 = torch.where(H[:M] > 0, plain.float(), torch.zeros_like(acc))
     assert (got2.float() - want2).abs().max().item() <= 2.0 ** -7 * want2.abs().max().item()
     assert gemm_bf16(X, W, relu=True, mask_src=H[:M].contiguous()) is None
+
+
+def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev):
+    """The fp32 GEMM moves X and W by asynchronous HBM -> LDS DMA with hand-counted waits
+    (gcn_gemm.hip, GEMM_H2_XLDS): a wait that is one too weak would show as run-to-run noise.
+    Many launches over inputs that give every persistent workgroup several tiles (cross-tile
+    prefetch), a ragged last tile, a row list and both epilogues — all launches must store the same
+    bits, and the plain result must match an fp64 product."""
+    from pygcn_amd.spmm import gemm_xw256
+    torch.manual_seed(11)
+    for M in (300_007, 70_001, 257):
+        X = torch.randn(M, 256, device=dev)
+        W = torch.randn(256, 256, device=dev) * 0.06
+        bias = torch.randn(256, device=dev) * 0.1
+        b = X.abs().max().reshape(1)
+        rows = torch.randint(0, M, (M // 2,), device=dev, dtype=torch.int32)
+        H = torch.relu(torch.randn(M, 256, device=dev))
+        variants = {
+            "plain": lambda: gemm_xw256(X, W, x_bound=b),
+            "epilogue": lambda: gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.3, seed=99),
+            "rows+mask": lambda: gemm_xw256(X, W, x_bound=b, rows=rows, mask_src=H, mask_scale=1.5),
+        }
+        for name, fn in variants.items():
+            first = fn()
+            assert torch.isfinite(first).all(), (name, M)
+            for _ in range(12):
+                assert torch.equal(fn(), first), (name, M)
+        ref = X[:2048].double() @ W.double()
+        got = variants["plain"]()[:2048].double()
+        assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
