@@ -36,7 +36,9 @@ class GCN(nn.Module):
         validation on other rows, as upstream's --fastmode uses it."""
         if rows is not None:
             return self._forward_rows(x, adj, rows, keep_full)
-        graph = self._one_node_graph(x, adj)
+        # (below ROWGRAD_MIN_ROWS vertices an epoch is launch-bound — Cora: ~1 ms — and the plain
+        #  layer-by-layer composition issues fewer launches than the node's generic fallbacks)
+        graph = self._one_node_graph(x, adj) if (x.dim() == 2 and x.shape[0] >= ROWGRAD_MIN_ROWS) else None
         if graph is not None:
             # the whole model as ONE autograd node (pygcn_amd/fused.py): its backward pass takes the
             # row-restricted route when the caller selected `output[idx_train]` (upstream's next

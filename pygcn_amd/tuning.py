@@ -14,7 +14,7 @@ stated; device-side twins live in gcn_spmm.hip (`use_row_flags`).
 | REASSOC_MAX_WIDTH_RATIO | 2 | first layer as (Â·X)·W (or the restricted product (Â·X)[R2]) only while Fin ≤ 2·Fout | the product gathers rows of width Fin instead of Fout: at 1433 → 16 (Cora) the transpose product is 90× cheaper |
 | MIN_ROWS | 2¹⁷ | row compaction / K-split weight gradient only from this many vertices | below ≈ 10⁵ rows every GEMM of the step is launch-bound (≤ 20 µs): C2 / C3-sized probes |
 | K_SPLIT | 128 | slabs of the hipBLASLt weight-gradient fallback | `tools/gemm_probe.py`: 8.7 ms vs 21.5 ms stream-K at N = 10⁷ |
-| ROWGRAD_MIN_ROWS | 16 384 | `model(x, adj)` returns a RowSelectable (structural `output[idx]` gradient) from this many vertices | Cora-sized epochs are launch-bound either way (0.8 ms); the wrapper subclass costs ≈ 30 µs of dispatch |
+| ROWGRAD_MIN_ROWS | 16 384 | `model(x, adj)` runs as one autograd node and returns a RowSelectable (structural `output[idx]` gradient) from this many vertices; below, the plain layer-by-layer composition | Cora-sized epochs are launch-bound (C2: 0.85 ms layer-by-layer against 1.04 ms through the node's generic fallbacks for 1433 → 16 → 7); the wrapper subclass costs ≈ 30 µs of dispatch |
 """
 from fractions import Fraction
 
