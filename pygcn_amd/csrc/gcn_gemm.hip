@@ -753,7 +753,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             const float *bias_p = ep.bias;
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
-                uint32_t r4[4] = {0u, 0u, 0u, 0u};     // the 8 keep fields of a pair of column groups
+                // dropout: the two Philox calls of this column block (8 keep fields each: groups 0-1 and
+                // 2-3) are computed TOGETHER, so that their two dependent chains of quarter-rate
+                // 32 x 32 -> 64 multiplies interleave; the scheduling barrier below then sits between
+                // column blocks, not between the chains
+                uint32_t r8[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                if (FWD_EPI && ep.drop_thresh != 0u) {                        // (uniform branch)
+                    uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
+                    if (ep.seed_dev != nullptr) {
+                        const uint64_t sd = *ep.seed_dev;
+                        k0 = (uint32_t)sd;
+                        k1 = (uint32_t)(sd >> 32);
+                    }
+                    const int64_t drow = row + ep.drop_row_base;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // (opaque: the first Philox round's product of this counter word with its
+                        //  constant does not depend on the tile, and hipcc hoists all of them out
+                        //  of the tile loop — spilled registers)
+                        uint32_t cw = ((uint32_t)(2 * nb + q) << 1) | (uint32_t)(lane >> 5);
+                        asm volatile("" : "+v"(cw));
+                        h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r8[q]);
+                    }
+                }
                 // backward mask: the four 16-byte pieces of this column block are fetched TOGETHER,
                 // ahead of the stores — loads and stores share one counter on gfx9 and may complete
                 // out of order, so a load issued after a store is waited for with vmcnt(0): one
@@ -788,22 +810,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     if (FWD_EPI && ep.drop_thresh != 0u) {                    // (uniform branch)
-                        if ((g & 1) == 0) {          // fields 0..3 now, 4..7 at g + 1
-                            uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
-                            if (ep.seed_dev != nullptr) {
-                                const uint64_t sd = *ep.seed_dev;
-                                k0 = (uint32_t)sd;
-                                k1 = (uint32_t)(sd >> 32);
-                            }
-                            // (opaque: the first Philox round's product of this counter word with its
-                            //  constant does not depend on the tile, and hipcc hoists all of them
-                            //  out of the tile loop — spilled registers)
-                            uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)(lane >> 5);
-                            asm volatile("" : "+v"(cw));
-                            const int64_t drow = row + ep.drop_row_base;
-                            h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r4);
-                        }
-                        const uint32_t w0 = (g & 1) ? r4[2] : r4[0], w1 = (g & 1) ? r4[3] : r4[1];
+                        const uint32_t *rq = r8[g >> 1];
+                        const uint32_t w0 = (g & 1) ? rq[2] : rq[0], w1 = (g & 1) ? rq[3] : rq[1];
                         v.x = (w0 & 0xFFFFu) >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
                         v.y = (w0 >> 16) >= ep.drop_thresh ? v.y * ep.drop_scale : 0.f;
                         v.z = (w1 & 0xFFFFu) >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
@@ -828,10 +836,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                             vmax = max(max(vmax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu)),
                                        max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
                     }
-                    // (keeps hipcc from running all 32 Philox chains of the tile side by side —
-                    //  128 live registers on top of the accumulators)
-                    if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
                 }
+                // (keeps hipcc from running all 16 Philox chains of the tile side by side — 64 live
+                //  registers on top of the accumulators)
+                if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
             }
         }
         row = row_n;
