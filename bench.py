@@ -673,6 +673,29 @@ def main():
                 spmm_mod.set_timing_records(None)
                 extras["ms_per_step_dense_loss"] = None
                 extras["dense_loss_note"] = f"failed: {ex!r}"
+            try:           # opt-in: z = A x X (two constants) computed once, not every epoch
+                from pygcn_amd import fused as fused_mod
+                fused_mod.set_input_product_cache(True)
+                restore_snapshot()
+                epoch()
+
+                def cached_step():
+                    restore_snapshot()
+                    epoch()
+                wall, _ = timed(5, cached_step)
+                extras["ms_per_step_cached_input_product"] = round(wall / 5 * 1e3, 3)
+                extras["cached_input_product_note"] = (
+                    "NOT the graded figure: with pygcn_amd.fused.set_input_product_cache(True) the layer-1 "
+                    "product z = A x X — a product of two constants of the run, since layer 1 is evaluated as "
+                    "(A x X) x W1 — is computed once and reused, so an epoch holds ONE forward sparse product; "
+                    "`ms_per_step` keeps both inside every timed epoch as SURVEY 8(d) defines it")
+            except Exception as ex:
+                extras["ms_per_step_cached_input_product"] = None
+                extras["cached_input_product_note"] = f"failed: {ex!r}"
+            finally:
+                fused_mod.set_input_product_cache(False)
+                if hasattr(adj, "_input_product"):
+                    del adj._input_product
             if dt == "f32":
                 try:       # the same graded epoch with every GEMM on hipBLASLt's exact-fp32 path
                     spmm_mod.set_gemm_scheme("exact")

@@ -141,6 +141,33 @@ def _operand_buffer(n, width, dtype, device, rows, values, count):
     return buf
 
 
+_CACHE_INPUT_PRODUCT = False
+
+
+def set_input_product_cache(enabled):
+    """OPT-IN (default off).  With layer 1 evaluated as (Â·X)·W1, its sparse product z = Â·X is a
+    product of two CONSTANTS of a training run (the adjacency and the feature matrix): switched on,
+    z is computed once per (graph, feature tensor, their version counters) and reused by every later
+    step — an epoch then contains ONE forward sparse product instead of two (−16 ms of 50 at C4).
+    The result is bitwise the same.  Off by default because the benchmark's epoch is defined with
+    both forward products inside it; bench.py reports the cached figure beside it."""
+    global _CACHE_INPUT_PRODUCT
+    _CACHE_INPUT_PRODUCT = bool(enabled)
+
+
+def input_product(graph, x):
+    """z = Â·X for the layer-1 input, from the per-graph cache when set_input_product_cache(True)
+    and neither the graph's values nor X changed since it was computed."""
+    if not _CACHE_INPUT_PRODUCT or x.requires_grad:
+        return spmm_csr(graph, x)
+    hit = getattr(graph, "_input_product", None)
+    if (hit is not None and hit[0]() is x and hit[1] == x._version and hit[2] == graph.val._version):
+        return hit[3]
+    z = spmm_csr(graph, x)
+    graph._input_product = (weakref.ref(x), x._version, graph.val._version, z)
+    return z
+
+
 def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     """Forward pass shared by the one-node functions: (tensor saved in place of x, h1, logp).
     Fills ctx.scale / x_bound / z_bound / h_bound / reassoc / has_bias / bias_dtypes."""
@@ -161,7 +188,7 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     h1 = h_bound = z = None
     ctx.z_bound = None
     if ctx.reassoc:
-        z = spmm_csr(graph, x)
+        z = input_product(graph, x)
         if bounded:
             ctx.z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
             h_bound = torch.zeros(1, dtype=torch.float32, device=x.device)   # max|h1|, exact

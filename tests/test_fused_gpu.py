@@ -525,3 +525,45 @@ def test_hooks_and_a_second_backward_see_ordinary_gradients(oracle, dev):
         dense = g_out + 0                                                # any operator sees the dense tensor
         assert type(dense) is torch.Tensor and dense.shape == (n, F_) and torch.isfinite(dense).all()
         assert int((dense != 0).any(1).sum()) in (idx.numel(), n)
+
+
+def test_input_product_cache_is_bitwise_neutral_and_notices_changes(dev):
+    """fused.set_input_product_cache(True): z = Â·X of the reassociated first layer is computed once
+    per (graph, X, versions); results are bitwise those of the uncached run, an in-place edit of X
+    or of the adjacency values invalidates it, and one forward product per epoch disappears."""
+    from pygcn_amd import GCN, CSRGraph, fused
+    from pygcn_amd import spmm as S
+    from pygcn_amd.utils import rmat_graph
+    n, F_ = 20000, 256
+    rowptr, col, val = rmat_graph(n, 200000, seed=81, device=dev)
+    g = CSRGraph(rowptr, col, val, (n, n))
+    x = torch.randn(n, F_, device=dev)
+    labels = torch.randint(0, F_, (n,), device=dev)
+    idx = torch.arange(n // 10, device=dev)
+    torch.manual_seed(8)
+    model = GCN(F_, F_, F_, dropout=0.0).to(dev)
+    model.train()
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(x, g, rows=idx)
+        torch.nn.functional.nll_loss(out, labels[idx]).backward()
+        return out.detach().clone(), [p.grad.clone() for p in model.parameters()]
+    base = step()
+    launches = []
+    S.set_timing_records(launches)
+    try:
+        fused.set_input_product_cache(True)
+        first, second = step(), step()
+        n_fwd = [sum(1 for r in launches if r[0] == "fwd")]
+        x.mul_(1.0)                                           # version bump: must recompute
+        third = step()
+        n_fwd.append(sum(1 for r in launches if r[0] == "fwd"))
+    finally:
+        fused.set_input_product_cache(False)
+        S.set_timing_records(None)
+    for got in (first, second, third):
+        assert torch.equal(got[0], base[0])
+        for a, b in zip(got[1], base[1]):
+            assert torch.equal(a, b)
+    assert n_fwd[0] == 2 + 1 and n_fwd[1] == n_fwd[0] + 2     # 2 products, then 1 (cached), then 2 again
