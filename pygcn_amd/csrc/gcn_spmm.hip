@@ -1159,7 +1159,12 @@ void launch_wide(const KParams &kp, bool is64, dim3 grid, hipStream_t s)
             else GCN_LAUNCH_WIDE(int32_t, true, 0);
         }
     } else {
-        if (xepi) {
+        if (kp.log_softmax && kp.cflag == nullptr && kp.cabsmax == nullptr) {
+            // the last layer of every forward pass: log_softmax only, without the row-flag / maximum
+            // code of the full-extras instantiation
+            if (is64) GCN_LAUNCH_WIDE(int64_t, false, 1);
+            else GCN_LAUNCH_WIDE(int32_t, false, 1);
+        } else if (xepi) {
             if (is64) GCN_LAUNCH_WIDE(int64_t, false, 2);
             else GCN_LAUNCH_WIDE(int32_t, false, 2);
         } else {
