@@ -213,12 +213,6 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     return (z if ctx.reassoc else x), h1, logp
 
 
-def _exact_absmax(t):
-    """max|t| as a device float [1] by one reduction pass (a TIGHT bound for the scaled GEMMs;
-    the analytic ‖Âᵀ‖∞·max|g| can be loose by orders of magnitude on hub-heavy graphs)."""
-    return torch.linalg.vector_norm(t, ord=float("inf")).float().reshape(1)
-
-
 def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     """Backward pass for a gradient that is non-zero on the loss rows only (module docstring):
     `grad_rows` [|rows|, C] in the user's row order, `out_rows` = logp at those rows.

@@ -35,7 +35,9 @@ for F, dt in ((256, torch.float32), (128, torch.bfloat16), (64, torch.float32)):
     out = torch.empty(n, F, device=dev, dtype=dt)
     for name, kw in (("plain", {}), ("bias", dict(bias=bias)),
                      ("bias+relu+dropout", dict(bias=bias, relu=True, dropout_p=0.5, seed=7)),
-                     ("bias+log_softmax", dict(bias=bias, log_softmax=True))):
+                     ("bias+log_softmax", dict(bias=bias, log_softmax=True)),
+                     ("bias+absmax", dict(bias=bias, c_absmax=torch.zeros(1, device=dev))),
+                     ("plain again", {})):
         t = t_of(lambda: spmm_csr(g, B, out=out, **kw))
         print(f"F {F:4d} {str(dt):15s} {name:20s} {t:8.3f} ms  {nnz / t / 1e6:7.3f} GEdge/s", flush=True)
     del B, out
