@@ -135,7 +135,64 @@ int main()
     std::printf("C_ABI_SMOKE nnz=%lld items=%lld chunks=%lld fwd_err=%.3e/%.3e bwd_err=%.3e/%.3e bad_dtype_rc=%d\n",
                 (long long)nnz, (long long)plan.n_items, (long long)plan.n_chunks, err, scale, err_t,
                 scale_t, bad);
-    const bool ok = err <= 1e-5 * scale && err_t <= 1e-5 * scale_t && bad == GCN_E_BADARG && plan.n_chunks > 0;
+    // ---- ABI 22: the epilogue's maximum side output, and the fused NLL + log_softmax backward sweep
+    float *d_amax = nullptr;
+    HIP_OK(hipMalloc((void **)&d_amax, sizeof(float)));
+    HIP_OK(hipMemsetAsync(d_amax, 0, sizeof(float), stream));
+    gcn_epilogue ep = {};                       // every option off ...
+    ep.bias = d_bias;
+    ep.log_softmax = 1;                         // ... except: store log_softmax(A·B + bias) rows
+    ep.c_absmax = d_amax;                       //             and report max|stored value|
+    GCN_OK(gcn_spmm_csr_ep(&plan, GCN_DTYPE_F32, d_B, F, d_C, F, F, &ep, ws, ws_bytes, stream));
+    std::vector<int64_t> target(n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) target[r] = (r % 13 == 0) ? -100 : (r * 7) % F;   // some ignored rows
+    int64_t kept = 0;
+    for (int64_t r = 0; r < n_rows; ++r) kept += target[r] >= 0;
+    const float coef = -1.f / (float)kept;
+    int64_t *d_target = to_dev(target);
+    std::vector<float> coef_h(1, coef);
+    float *d_coef = to_dev(coef_h), *d_gp = nullptr, *d_colsum = nullptr;
+    HIP_OK(hipMalloc((void **)&d_gp, n_rows * F * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_colsum, F * sizeof(float)));
+    const size_t sweep_bytes = gcn_bwd_colsum_workspace_bytes(n_rows, F, GCN_DTYPE_F32);
+    void *sweep_ws = nullptr;
+    HIP_OK(hipMalloc(&sweep_ws, sweep_bytes + 16));
+    GCN_OK(gcn_nll_log_softmax_backward_colsum(GCN_DTYPE_F32, d_target, d_coef, d_C, d_gp, d_colsum, n_rows, F,
+                                               sweep_ws, sweep_bytes, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<float> logp(n_rows * F), gp(n_rows * F), colsum(F);
+    float amax = 0.f;
+    HIP_OK(hipMemcpy(logp.data(), d_C, logp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(gp.data(), d_gp, gp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(colsum.data(), d_colsum, F * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&amax, d_amax, sizeof(float), hipMemcpyDeviceToHost));
+    double err_lse = 0, err_gp = 0, scale_gp = 0, err_cs = 0, scale_cs = 0;
+    float want_amax = 0.f;
+    std::vector<double> cs(F, 0.0);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        double se = 0;
+        for (int64_t f = 0; f < F; ++f) {
+            se += std::exp((double)logp[r * F + f]);
+            want_amax = std::fmax(want_amax, std::fabs(logp[r * F + f]));
+        }
+        err_lse = std::fmax(err_lse, std::fabs(se - 1.0));                   // rows of exp(logp) sum to 1
+        for (int64_t f = 0; f < F; ++f) {
+            const double ref = target[r] < 0 ? 0.0
+                : (double)coef * ((f == target[r] ? 1.0 : 0.0) - std::exp((double)logp[r * F + f]));
+            err_gp = std::fmax(err_gp, std::fabs((double)gp[r * F + f] - ref));
+            scale_gp = std::fmax(scale_gp, std::fabs(ref));
+            cs[f] += ref;
+        }
+    }
+    for (int64_t f = 0; f < F; ++f) {
+        err_cs = std::fmax(err_cs, std::fabs((double)colsum[f] - cs[f]));
+        scale_cs = std::fmax(scale_cs, std::fabs(cs[f]));
+    }
+    std::printf("C_ABI_SMOKE abi22 lse_err=%.3e gp_err=%.3e/%.3e colsum_err=%.3e/%.3e amax=%g (want %g)\n", err_lse,
+                err_gp, scale_gp, err_cs, scale_cs, amax, want_amax);
+    const bool ok22 = err_lse <= 1e-5 && err_gp <= 1e-5 * scale_gp && err_cs <= 2e-5 * scale_cs + 1e-9 &&
+                      amax == want_amax;
+    const bool ok = ok22 && err <= 1e-5 * scale && err_t <= 1e-5 * scale_t && bad == GCN_E_BADARG && plan.n_chunks > 0;
     std::printf(ok ? "C_ABI_SMOKE OK\n" : "C_ABI_SMOKE FAILED\n");
     return ok ? 0 : 5;
 }
