@@ -286,6 +286,18 @@ int gcn_nll_log_softmax_backward_colsum(int dtype, const int64_t *target, const 
                                         int64_t F, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * SDDMM on the pattern of `plan`: out_vals[e] = < G[row(e), :], B[col[e], :] > for every stored
+ * entry e (fp32 results; G [n_rows, F] and B [n_cols, F] row-major fp32 or bf16, leading dimensions
+ * in elements).  The gradient of the adjacency VALUES for a caller that sets adj.requires_grad —
+ * PyTorch's `mm` derivative for a sparse first operand, (grad · mat2^T) sampled on self's pattern;
+ * the reference never needs it (its adj is a constant: pygcn/train.py:80,123), SURVEY row f4 lists
+ * it as optional.  Uses the schedule of `plan` (items, long-row chunks); no workspace, no atomics,
+ * deterministic.  (ABI 22.)
+ */
+int gcn_sddmm_csr(const gcn_csr_plan *plan, int dtype, const void *G, int64_t ldg, const void *B,
+                  int64_t ldb, int64_t F, float *out_vals, void *stream);
+
+/*
  * CSR(A^T) on the HOST from CSR(A) on the HOST: stable counting sort by column, so each row of
  * A^T lists its entries in increasing source-row order (deterministic backward sums).
  * rowptr_t[n_cols+1] has the width of rowptr; col_t[nnz]; val_t[nnz].

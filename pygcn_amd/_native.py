@@ -70,7 +70,7 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_gemm_bf16_workspace_bytes", "gcn_gemm_xw_bf16",
            "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32",
            "gcn_nll_log_softmax_backward_colsum", "gcn_gemm_atg_bf16_workspace_bytes",
-           "gcn_gemm_atg_bf16")
+           "gcn_gemm_atg_bf16", "gcn_sddmm_csr")
 
 _lib = None
 
@@ -206,6 +206,10 @@ def lib():
                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_sddmm_csr.restype = ctypes.c_int
+    L.gcn_sddmm_csr.argtypes = [ctypes.POINTER(GcnCsrPlan), ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                ctypes.c_void_p]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

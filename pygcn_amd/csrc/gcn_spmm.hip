@@ -1285,6 +1285,90 @@ int plan_walk(const IdxT *rp, int64_t n_rows, int item_cost, int long_thresh, in
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// SDDMM: out[e] = < G[row(e), :], B[col[e], :] > for every stored entry e of the CSR pattern — the
+// gradient of the adjacency VALUES when a caller sets adj.requires_grad (PyTorch's `mm` derivative
+// for a sparse first operand: grad_self = (grad · mat2ᵀ) sampled on self's pattern,
+// derivatives.yaml `mm` / pygcn/layers.py:34).  The reference never needs it (adj is a loaded
+// constant, pygcn/train.py:80,123); SURVEY row f4 lists it as optional.
+// Same work units as the product (row-batch items and long-row chunks, one per wave); a wave keeps
+// the row of G it works on in registers where the row fits one wave instruction, gathers U = 4
+// rows of B at a time (16 B per lane, row address wave-uniform) and reduces the 4 partial dot
+// products across the wave.  Gather-bound like the product: nnz·(F·s) + n·(F·s) bytes.
+// ------------------------------------------------------------------------------------------
+struct SddmmParams {
+    const void *rowptr;
+    const int32_t *col;
+    const int32_t *items;
+    const int32_t *chunk_row;
+    const int64_t *chunk_e0;
+    const void *G;
+    const void *B;
+    float *out;
+    int64_t ldg, ldb;      // elements
+    int32_t F, n_total, n_chunks, long_thresh;
+};
+
+template <typename T, int VEC, typename IdxT>
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void sddmm_kernel(SddmmParams p)
+{
+    typedef typename Elem<T, VEC>::Raw Raw;
+    constexpr int U = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item =
+        blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (item >= p.n_total) return;
+    const IdxT *__restrict__ rp = (const IdxT *)p.rowptr;
+    int ra, rb;
+    int64_t e_lo = -1, e_hi = -1;                   // entry window of a chunk (whole rows otherwise)
+    if (item < p.n_chunks) {
+        ra = p.chunk_row[item];
+        rb = ra + 1;
+        e_lo = p.chunk_e0[item];
+        e_hi = min(e_lo + (int64_t)p.long_thresh, (int64_t)rp[ra + 1]);
+    } else {
+        const int it = item - p.n_chunks;
+        ra = p.items[2 * it];
+        rb = p.items[2 * it + 1];
+    }
+    const int slab = kWave * VEC;                   // elements one wave instruction covers
+    for (int r = ra; r < rb; ++r) {                 // (wave-uniform loop)
+        const int64_t es = e_lo >= 0 ? e_lo : (int64_t)rp[r];
+        const int64_t ee = e_lo >= 0 ? e_hi : (int64_t)rp[r + 1];
+        if (es >= ee) continue;
+        const T *grow = (const T *)p.G + (int64_t)r * p.ldg;
+        for (int64_t e = es; e < ee; e += U) {
+            const int cnt = (int)min((int64_t)U, ee - e);
+            float part[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) part[u] = 0.f;
+            for (int f0 = lane * VEC; f0 < p.F; f0 += slab) {
+                float g[VEC];
+                Elem<T, VEC>::unpack(*(const Raw *)(grow + f0), g);      // (L1-resident across the row)
+                Raw braw[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = p.col[e + (u < cnt ? u : 0)];          // (uniform: scalar load)
+                    braw[u] = *(const Raw *)((const T *)p.B + (int64_t)c * p.ldb + f0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float b[VEC];
+                    Elem<T, VEC>::unpack(braw[u], b);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) part[u] = fmaf(g[i], b[i], part[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float s = group_sum<kWave>(part[u]);
+                if (lane == u && u < cnt) p.out[e + u] = s;
+            }
+        }
+    }
+}
+
 }   // namespace
 
 // shared with gcn_ingest.hip
@@ -1597,6 +1681,65 @@ int gcn_nll_log_softmax_backward_colsum(int dtype, const int64_t *target, const 
     return bwd_colsum_impl("gcn_nll_log_softmax_backward_colsum", 3, dtype, nullptr, out, grad_pre,
                            colsum, n_rows, F, 1.f, nullptr, nullptr, 0, workspace, workspace_bytes,
                            stream, target, coef);
+}
+
+int gcn_sddmm_csr(const gcn_csr_plan *plan, int dtype, const void *G, int64_t ldg, const void *B,
+                  int64_t ldb, int64_t F, float *out_vals, void *stream)
+{
+    if (plan == nullptr) return fail(GCN_E_BADARG, "gcn_sddmm_csr: plan is NULL");
+    if (dtype != GCN_DTYPE_F32 && dtype != GCN_DTYPE_BF16)
+        return fail(GCN_E_BADARG, "gcn_sddmm_csr: unknown dtype");
+    if (plan->n_rows < 0 || plan->n_cols < 0 || plan->nnz < 0 || F < 0 || F > INT32_MAX)
+        return fail(GCN_E_BADARG, "gcn_sddmm_csr: negative size");
+    if (plan->nnz == 0) return 0;
+    if (G == nullptr || B == nullptr || out_vals == nullptr || plan->rowptr == nullptr ||
+        plan->col == nullptr || plan->items == nullptr)
+        return fail(GCN_E_BADARG, "gcn_sddmm_csr: NULL pointer");
+    if (plan->n_chunks > 0 && (plan->chunk_row == nullptr || plan->chunk_e0 == nullptr))
+        return fail(GCN_E_BADARG, "gcn_sddmm_csr: plan has long rows but NULL chunk arrays");
+    if (ldg < F || ldb < F) return fail(GCN_E_BADARG, "gcn_sddmm_csr: ldg / ldb smaller than F");
+    hipStream_t s = (hipStream_t)stream;
+    if (F == 0) {
+        hipError_t e = hipMemsetAsync(out_vals, 0, (size_t)plan->nnz * sizeof(float), s);
+        return e == hipSuccess ? 0 : fail_hip(e, "gcn_sddmm_csr");
+    }
+    SddmmParams sp;
+    sp.rowptr = plan->rowptr;
+    sp.col = plan->col;
+    sp.items = plan->items;
+    sp.chunk_row = plan->chunk_row;
+    sp.chunk_e0 = plan->chunk_e0;
+    sp.G = G;
+    sp.B = B;
+    sp.out = out_vals;
+    sp.ldg = ldg;
+    sp.ldb = ldb;
+    sp.F = (int32_t)F;
+    sp.n_total = (int32_t)(plan->n_items + plan->n_chunks);
+    sp.n_chunks = (int32_t)plan->n_chunks;
+    sp.long_thresh = plan->long_thresh > 0 ? plan->long_thresh : kDefaultLongThresh;
+    const bool is64 = plan->rowptr_is64 != 0;
+    const size_t es = dtype == GCN_DTYPE_BF16 ? 2 : 4;
+    const int64_t vw = dtype == GCN_DTYPE_BF16 ? 8 : 4;
+    const bool vec_ok = (F % vw == 0) && (((uintptr_t)G | (uintptr_t)B) % 16 == 0) &&
+                        ((ldg * (int64_t)es) % 16 == 0) && ((ldb * (int64_t)es) % 16 == 0);
+    const dim3 grid((unsigned)((sp.n_total + kWavesPerBlock - 1) / kWavesPerBlock)), block(kWave * kWavesPerBlock);
+#define GCN_LAUNCH_SDDMM(T, V)                                                             \
+    do {                                                                                   \
+        if (is64) hipLaunchKernelGGL((sddmm_kernel<T, V, int64_t>), grid, block, 0, s, sp); \
+        else hipLaunchKernelGGL((sddmm_kernel<T, V, int32_t>), grid, block, 0, s, sp);      \
+    } while (0)
+    if (dtype == GCN_DTYPE_F32) {
+        if (vec_ok) GCN_LAUNCH_SDDMM(float, 4);
+        else GCN_LAUNCH_SDDMM(float, 1);
+    } else {
+        if (vec_ok) GCN_LAUNCH_SDDMM(bf16_t, 8);
+        else GCN_LAUNCH_SDDMM(bf16_t, 1);
+    }
+#undef GCN_LAUNCH_SDDMM
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "gcn_sddmm_csr launch");
+    return 0;
 }
 
 int gcn_csr_transpose_host(const void *rowptr_host, int rowptr_is64, const int32_t *col,

@@ -69,26 +69,52 @@ def _(rowptr, col, val, n_cols):
     return rowptr.new_empty((n_cols + 1,)), col.new_empty(col.shape), val.new_empty(val.shape)
 
 
+@torch.library.custom_op("pygcn_amd::sddmm_csr", mutates_args=(), device_types="cuda")
+def sddmm_csr_op(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, G: torch.Tensor,
+                 B: torch.Tensor, n_cols: int) -> torch.Tensor:
+    """grad_val[e] = < G[row(e), :], B[col[e], :] > on the pattern of the adjacency held in these
+    arrays (C-ABI gcn_sddmm_csr): the gradient of the adjacency values of spmm_csr — only computed
+    when a caller sets `val.requires_grad` (the reference never does: pygcn/train.py:80,123)."""
+    graph = graph_for_arrays(rowptr, col, val, (rowptr.numel() - 1, n_cols))
+    return _spmm.sddmm_csr(graph, G, B).to(val.dtype)
+
+
+@sddmm_csr_op.register_kernel("cpu")
+def _(rowptr, col, val, G, B, n_cols):
+    raise RuntimeError(_NO_CPU.replace("spmm_csr", "sddmm_csr"))
+
+
+@sddmm_csr_op.register_fake
+def _(rowptr, col, val, G, B, n_cols):
+    return val.new_empty(val.shape)
+
+
 def _setup_context(ctx, inputs, output):
     rowptr, col, val, B, bias, n_cols, relu = inputs
     ctx.n_cols, ctx.relu = n_cols, bool(relu)
     ctx.bias_dtype = bias.dtype if bias is not None else None
-    ctx.save_for_backward(rowptr, col, val, *([output] if relu else []))
+    ctx.val_grad = bool(val.requires_grad)
+    # (B is kept only when the adjacency values themselves need a gradient: grad_val is an SDDMM
+    #  of grad_C and B; the reference's adjacency is a constant and never asks for it)
+    ctx.save_for_backward(rowptr, col, val, *([output] if relu else []), *([B] if ctx.val_grad else []))
 
 
 def _backward(ctx, grad_out):
     # written with operators only (no raw pointers), so AOT autograd can trace it
     rowptr, col, val = ctx.saved_tensors[:3]
-    grad_B = grad_bias = None
+    grad_B = grad_bias = grad_val = None
     if ctx.relu:
         grad_out = torch.where(ctx.saved_tensors[3] > 0, grad_out, torch.zeros_like(grad_out))
+    if ctx.val_grad and ctx.needs_input_grad[2]:
+        grad_val = torch.ops.pygcn_amd.sddmm_csr(rowptr, col, val, grad_out.contiguous(),
+                                                 ctx.saved_tensors[-1], ctx.n_cols)
     if ctx.needs_input_grad[3]:
         rp_t, col_t, val_t = torch.ops.pygcn_amd.csr_transpose(rowptr, col, val, ctx.n_cols)
         grad_B = torch.ops.pygcn_amd.spmm_csr(rp_t, col_t, val_t, grad_out.contiguous(), None,
                                               rowptr.shape[0] - 1, False)
     if ctx.bias_dtype is not None and ctx.needs_input_grad[4]:
         grad_bias = grad_out.sum(0).to(ctx.bias_dtype)
-    return None, None, None, grad_B, grad_bias, None, None
+    return None, None, grad_val, grad_B, grad_bias, None, None
 
 
 spmm_csr_op.register_autograd(_backward, setup_context=_setup_context)

@@ -139,6 +139,34 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
     return out
 
 
+def sddmm_csr(graph, G, B):
+    """values[e] = < G[row(e), :], B[col[e], :] > for every stored entry e of `graph` (fp32 [nnz]) —
+    the gradient of the adjacency VALUES of C = A · B for the gradient G of C (C-ABI gcn_sddmm_csr;
+    PyTorch's `mm` derivative for a sparse first operand, sampled on A's pattern).  The reference
+    never needs it (adj is a constant, pygcn/train.py:80,123); SURVEY row f4 lists it as optional."""
+    if not isinstance(graph, CSRGraph):
+        raise RuntimeError("sddmm_csr: graph must be a CSRGraph")
+    _require_cuda(G, "G")
+    _require_cuda(B, "B")
+    if (G.dim() != 2 or B.dim() != 2 or G.shape[0] != graph.shape[0] or B.shape[0] != graph.shape[1]
+            or G.shape[1] != B.shape[1] or G.dtype != B.dtype or G.dtype not in _DTYPES
+            or G.device != graph.device or B.device != graph.device):
+        raise RuntimeError(f"sddmm_csr: adj {graph.shape}, G {tuple(G.shape)} {G.dtype}, B {tuple(B.shape)} {B.dtype}")
+    if G.shape[1] > 0 and G.stride(1) != 1:
+        G = G.contiguous()
+    if B.shape[1] > 0 and B.stride(1) != 1:
+        B = B.contiguous()
+    out = torch.empty(graph.nnz, dtype=torch.float32, device=G.device)
+    if graph.nnz == 0:
+        return out
+    with torch.cuda.device(G.device):
+        rc = _native.lib().gcn_sddmm_csr(graph.plan(), _DTYPES[G.dtype], G.data_ptr(), G.stride(0),
+                                         B.data_ptr(), B.stride(0), G.shape[1], out.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, "gcn_sddmm_csr")
+    return out
+
+
 def log_softmax_fusable(F, dtype):
     """True when log_softmax over rows of width F can run inside the SpMM's store: the whole row
     must sit in one wavefront (F <= 64, or 16-byte lanes with F / lane width <= 64; a freshly

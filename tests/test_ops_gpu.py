@@ -110,3 +110,31 @@ def test_train_script_runs_like_the_reference_cli(dev):
                        cwd=os.path.join(ROOT, "pygcn_amd"), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and r.stdout.count("Epoch:") == 3, r.stderr[-2000:]
+
+
+def test_operator_gives_the_adjacency_values_a_gradient_when_asked(dev):
+    """`val.requires_grad_()` on the registered operator: grad_val through pygcn_amd::sddmm_csr, checked
+    against the reference's own arithmetic library on CPU — `torch.sparse.mm` with a sparse operand
+    that requires grad (the `mm` derivative of derivatives.yaml the survey cites for row f4) — and
+    opcheck'ed.  The reference itself never asks for it (pygcn/train.py:80,123)."""
+    import pygcn_amd  # noqa: F401  (registers the operators)
+    from pygcn_amd.utils import rmat_graph
+    n, F = 3000, 64
+    rowptr, col, val = rmat_graph(n, 30000, seed=13, device="cpu")
+    torch.manual_seed(0)
+    B, G = torch.randn(n, F), torch.randn(n, F)
+    row = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).long())
+    v_cpu = val.clone().requires_grad_(True)
+    b_cpu = B.clone().requires_grad_(True)
+    a_cpu = torch.sparse_coo_tensor(torch.stack([row, col.long()]), v_cpu, (n, n))
+    torch.sparse.mm(a_cpu, b_cpu).backward(G)
+    v = val.to(dev).requires_grad_(True)
+    b = B.to(dev).requires_grad_(True)
+    out = torch.ops.pygcn_amd.spmm_csr(rowptr.to(dev), col.to(dev), v, b, None, n, False)
+    out.backward(G.to(dev))
+    scale = v_cpu.grad.abs().max().item()
+    assert (v.grad.cpu() - v_cpu.grad).abs().max().item() <= 1e-5 * scale
+    assert (b.grad.cpu() - b_cpu.grad).abs().max().item() <= 1e-5 * b_cpu.grad.abs().max().item()
+    torch.library.opcheck(torch.ops.pygcn_amd.sddmm_csr.default,
+                          (rowptr.to(dev), col.to(dev), val.to(dev), G.to(dev), B.to(dev), n),
+                          test_utils=("test_schema", "test_faketensor"))

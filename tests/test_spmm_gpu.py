@@ -1203,3 +1203,28 @@ def test_product_reports_its_own_absmax(oracle, dev, F, dtype):
         m = torch.zeros(1, device=dev)
         spmm_csr(g, Bn, c_absmax=m)
         assert not torch.isfinite(m).all()
+
+
+@pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (7, torch.float32),
+                                     (300, torch.float32), (128, torch.bfloat16)])
+def test_sddmm_on_the_adjacency_pattern(oracle, dev, F, dtype):
+    """the gradient of the adjacency VALUES, grad_val[e] = <G[row(e)],
+    B[col[e]]> on A's pattern (gcn_sddmm_csr) — PyTorch's `mm` derivative for a sparse first
+    operand.  Against float64 numpy on the same (bf16-rounded) operands: rows of 1 ... 1500 entries
+    incl. the chunked long-row work units, empty rows, vector and scalar element paths."""
+    from pygcn_amd.spmm import sddmm_csr
+    n, m = 2500, 1800
+    a = _skewed_csr(oracle, n, m, 6, seed=25, hubs=((3, 1500), (900, 700)), empties=40)
+    g = _graph(a, dev)
+    G = torch.from_numpy(gin.dense((n, F), 31)).to(dtype)
+    B = torch.from_numpy(gin.dense((m, F), 32)).to(dtype)
+    got = sddmm_csr(g, G.to(dev), B.to(dev))
+    assert got.dtype == torch.float32 and got.shape == (a.nnz,)
+    row = np.repeat(np.arange(n), np.diff(a.rowptr))
+    ref = (G.double().numpy()[row] * B.double().numpy()[a.col]).sum(1)
+    assert_normwise(got.cpu(), ref, 1e-5, f"sddmm F={F} {dtype}")
+    # the same through unaligned operands (scalar element path): a column slice with an odd pitch
+    if dtype == torch.float32 and F > 8:
+        Gs, Bs = G.to(dev)[:, 1:F - 2], B.to(dev)[:, 1:F - 2]
+        ref2 = (G.double().numpy()[row][:, 1:F - 2] * B.double().numpy()[a.col][:, 1:F - 2]).sum(1)
+        assert_normwise(sddmm_csr(g, Gs, Bs).cpu(), ref2, 1e-5, "sddmm, unaligned slices")
