@@ -74,7 +74,9 @@ typedef struct gcn_csr_plan {
 
 /* ABI history: 21 = round 2's surface.  22 (round 3): the dropout keep function draws eight 16-bit
  * fields per Philox call instead of four 32-bit words and takes a row base (drop_row_base in both
- * epilogue structs); + gcn_nll_log_softmax_backward_colsum.  The three options that leave
+ * epilogue structs) and the product can report max|result| (gcn_epilogue.c_absmax); new entry
+ * points gcn_nll_log_softmax_backward_colsum, gcn_gemm_atg_bf16, gcn_sddmm_csr; gcn_gemm_xw_bf16
+ * takes a backward mask.  The three options that leave
  * rows of an output unwritten (c_skip_zero_rows, c_row_select, skip_zero_rows of the backward
  * sweeps) are EXPERIMENTAL: the product uses them only inside single autograd nodes that own both
  * the producer and every consumer of such a tensor (pygcn_amd/fused.py). */
