@@ -218,7 +218,7 @@ def test_sparse_gradient_exchange_with_bitmap_hint(tmp_path, oracle):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_declared_loss_rows_make_the_gradient_exchange_static(world, tmp_path, oracle):
     """ShardedGCN.declare_loss_rows: the layer-by-layer path's row-sparse backward exchange runs
     its count exchange once instead of every step — same gradients (oracle parity in the worker)."""
@@ -228,7 +228,7 @@ def test_declared_loss_rows_make_the_gradient_exchange_static(world, tmp_path, o
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_compressed_hidden_layer_exchange(world, tmp_path, oracle):
     """ShardedGraph(compress_hidden=True): the halo rows of a hidden activation travel as bitmask +
     non-zero values and meet the weight on arrival (product_hidden / ShardedHiddenLayerFunction);
