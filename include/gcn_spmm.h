@@ -75,7 +75,8 @@ typedef struct gcn_csr_plan {
 /* ABI history: 21 = round 2's surface.  22 (round 3): the dropout keep function draws eight 16-bit
  * fields per Philox call instead of four 32-bit words and takes a row base (drop_row_base in both
  * epilogue structs) and the product can report max|result| (gcn_epilogue.c_absmax); new entry
- * points gcn_nll_log_softmax_backward_colsum, gcn_gemm_atg_bf16, gcn_sddmm_csr; gcn_gemm_xw_bf16
+ * points gcn_nll_log_softmax_backward_colsum, gcn_gemm_atg_bf16, gcn_sddmm_csr, gcn_rows_pack_count /
+ * gcn_rows_pack_values / gcn_rows_unpack / gcn_bits_row_counts; gcn_gemm_xw_bf16
  * takes a backward mask.  The three options that leave
  * rows of an output unwritten (c_skip_zero_rows, c_row_select, skip_zero_rows of the backward
  * sweeps) are EXPERIMENTAL: the product uses them only inside single autograd nodes that own both
@@ -454,6 +455,31 @@ size_t gcn_gemm_atg_bf16_workspace_bytes(int64_t n_list, int64_t K, int64_t N);
 int gcn_gemm_atg_bf16(const void *A, int64_t lda, const int32_t *rows_a, const void *G, int64_t ldg,
                       const int32_t *rows_g, int64_t n_list, int64_t K, int64_t N, float *out,
                       int64_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Rows of a mostly-zero activation as BITMASK + NON-ZERO VALUES — the wire format of the multi-GPU
+ * path's compressed hidden-layer halo exchange (pygcn_amd/sharded.py; the input of the second
+ * GraphConvolution layer is relu + dropout output, pygcn/models.py:48,50: >= 75 % zeros in
+ * training).  The reference has no multi-device code; SURVEY §8(e).  (ABI 22.)
+ *   bit j of bits[r*(F/32) + w] is set iff element 32*w + j of row r is non-zero; vals holds the
+ *   non-zero elements in row-major order, row r starting at offsets[r].
+ * gcn_rows_pack_count : reads rows `rows[r]` (NULL = rows 0..m-1) of src [*, ld] (fp32 or bf16, F
+ *   a multiple of 32, ld a multiple of 4, 16-byte aligned base); writes bits [m, F/32] and
+ *   counts [m] (non-zeros per row).  The caller scans counts into offsets (int64, exclusive).
+ * gcn_rows_pack_values: writes vals [offsets[m-1] + counts[m-1]] (element type of src).
+ * gcn_rows_unpack     : dst [m, ldd] (every element written) from bits, offsets, vals.
+ * gcn_bits_row_counts : counts [m] = set bits per row of bits [m, words] (the receiver's side:
+ *   the wire carries bits and values only; it scans these counts into its own offsets).
+ * -0.0 counts as zero (it compares equal to 0) and arrives as +0.0; NaN is non-zero.
+ * Deterministic; DEVICE pointers; asynchronous on `stream`.
+ */
+int gcn_rows_pack_count(int dtype, const void *src, int64_t ld, const int64_t *rows, int64_t m, int64_t F,
+                        uint32_t *bits, int32_t *counts, void *stream);
+int gcn_rows_pack_values(int dtype, const void *src, int64_t ld, const int64_t *rows, int64_t m, int64_t F,
+                         const int64_t *offsets, void *vals, void *stream);
+int gcn_rows_unpack(int dtype, const uint32_t *bits, const int64_t *offsets, const void *vals, int64_t m,
+                    int64_t F, void *dst, int64_t ldd, void *stream);
+int gcn_bits_row_counts(const uint32_t *bits, int64_t m, int64_t words, int32_t *counts, void *stream);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,8 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_gemm_bf16_workspace_bytes", "gcn_gemm_xw_bf16",
            "gcn_gemm_atg256_workspace_bytes", "gcn_gemm_atg256_f32",
            "gcn_nll_log_softmax_backward_colsum", "gcn_gemm_atg_bf16_workspace_bytes",
-           "gcn_gemm_atg_bf16", "gcn_sddmm_csr")
+           "gcn_gemm_atg_bf16", "gcn_sddmm_csr", "gcn_rows_pack_count", "gcn_rows_pack_values",
+           "gcn_rows_unpack", "gcn_bits_row_counts")
 
 _lib = None
 
@@ -210,6 +211,15 @@ def lib():
     L.gcn_sddmm_csr.argtypes = [ctypes.POINTER(GcnCsrPlan), ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                 ctypes.c_void_p]
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    L.gcn_rows_pack_count.restype = ctypes.c_int
+    L.gcn_rows_pack_count.argtypes = [ctypes.c_int, vp, i64, vp, i64, i64, vp, vp, vp]
+    L.gcn_rows_pack_values.restype = ctypes.c_int
+    L.gcn_rows_pack_values.argtypes = [ctypes.c_int, vp, i64, vp, i64, i64, vp, vp, vp]
+    L.gcn_rows_unpack.restype = ctypes.c_int
+    L.gcn_rows_unpack.argtypes = [ctypes.c_int, vp, vp, vp, i64, i64, vp, i64, vp]
+    L.gcn_bits_row_counts.restype = ctypes.c_int
+    L.gcn_bits_row_counts.argtypes = [vp, i64, i64, vp, vp]
     if L.gcn_abi_version() != GCN_ABI_VERSION:
         raise NativeLibraryError(f"{LIB_PATH}: ABI version {L.gcn_abi_version()} != "
                                  f"{GCN_ABI_VERSION}; rebuild with `python -m pygcn_amd.build`")

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRCS = [os.path.join(HERE, "csrc", f) for f in ("gcn_spmm.hip", "gcn_ingest.hip", "gcn_gemm.hip", "gcn_plan.hip")]
+SRCS = [os.path.join(HERE, "csrc", f) for f in ("gcn_spmm.hip", "gcn_ingest.hip", "gcn_gemm.hip", "gcn_plan.hip", "gcn_pack.hip")]
 OUT = os.path.join(HERE, "csrc", "libgcn_spmm.so")
 ARCH = "gfx950"
 

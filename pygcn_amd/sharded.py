@@ -58,8 +58,8 @@ import torch.distributed as dist
 
 from . import tuning
 from .graph import CSRGraph
-from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, pack_row_flags, spmm_csr,
-                   unpack_row_flags)
+from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, pack_row_flags, rows_pack,
+                   rows_unpack, spmm_csr, unpack_row_flags)
 
 
 def partition_rows(rowptr, world):
@@ -326,13 +326,18 @@ class HaloExchange:
         F, dev, W = local.shape[1], local.device, self.world
         if W == 1:
             return None
-        rows = local.index_select(0, self.send_idx)                       # [n_send, F]
-        mask = rows != 0
-        bits = pack_bits(mask)                                            # int32 [n_send, F / 32]
-        vals = rows[mask]                                                 # non-zero values, row-major
-        per_row = mask.sum(1)
-        csum = torch.zeros(self.n_send + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(per_row, 0, out=csum[1:])
+        if local.is_cuda:
+            # HIP path: the requested rows are read in place (no gathered copy), two passes
+            bits, csum, vals = rows_pack(local, self.send_idx)
+        else:
+            # (CPU tensors — the gloo rehearsals of this exchange: the same format with torch ops)
+            rows = local.index_select(0, self.send_idx)                   # [n_send, F]
+            mask = rows != 0
+            bits = pack_bits(mask)                                        # int32 [n_send, F / 32]
+            vals = rows[mask]                                             # non-zero values, row-major
+            per_row = mask.sum(1)
+            csum = torch.zeros(self.n_send + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(per_row, 0, out=csum[1:])
         off = torch.tensor(self.send_off + [self.n_send], dtype=torch.int64, device=dev)
         vcut = csum[off]                                                  # value offsets per peer
         mine = (vcut[1:] - vcut[:-1]).contiguous()
@@ -361,10 +366,13 @@ class HaloExchange:
             return like.new_zeros((self.n_halo, like.shape[1]))
         pending, _keep, bits_halo, parts, F, dtype = state
         _p2p_end(pending)
+        if not self.n_halo:
+            return torch.zeros((0, F), dtype=dtype, device=bits_halo.device)
+        vals = torch.cat([parts[r] for r in range(self.world) if r != self.rank])       # halo (owner) order
+        if bits_halo.is_cuda:
+            return rows_unpack(bits_halo, vals, F)
         halo = torch.zeros((self.n_halo, F), dtype=dtype, device=bits_halo.device)
-        if self.n_halo:
-            vals = torch.cat([parts[r] for r in range(self.world) if r != self.rank])   # halo (owner) order
-            halo[unpack_bits(bits_halo, F)] = vals
+        halo[unpack_bits(bits_halo, F)] = vals
         return halo
 
     def exchange_sparse(self, local, row_nonzero, static_key=None):

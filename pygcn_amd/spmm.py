@@ -167,6 +167,63 @@ def sddmm_csr(graph, G, B):
     return out
 
 
+def rows_pack(src, rows=None):
+    """Rows `rows` (int64 index tensor; None = all) of `src` [*, F] (fp32 / bf16, F a multiple of 32)
+    as BITMASK + NON-ZERO VALUES (C-ABI gcn_rows_pack_count / gcn_rows_pack_values; wire format of
+    the compressed halo exchange, pygcn_amd/sharded.py): -> (bits int32 [m, F/32], offsets int64
+    [m + 1] (exclusive scan of the per-row counts), vals [offsets[-1]]).  Sizing `vals` reads the
+    total count on the host (one synchronisation; the exchange needs the counts there anyway)."""
+    _require_cuda(src, "src")
+    if src.dim() != 2 or src.dtype not in _DTYPES or src.shape[1] % 32 != 0 or src.shape[1] == 0:
+        raise RuntimeError(f"rows_pack: src {tuple(src.shape)} {src.dtype}: 2-D fp32 / bf16, width a multiple of 32")
+    if src.stride(1) != 1 or src.stride(0) % 4 != 0:
+        src = src.contiguous()
+    F, dev = src.shape[1], src.device
+    if rows is not None:
+        if rows.dtype != torch.int64 or rows.device != dev or rows.dim() != 1:
+            raise RuntimeError("rows_pack: rows must be a 1-D int64 tensor on the device of src")
+        rows = rows.contiguous()
+    m = src.shape[0] if rows is None else rows.numel()
+    bits = torch.empty((m, F // 32), dtype=torch.int32, device=dev)
+    counts = torch.empty(m, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    L, dt = _native.lib(), _DTYPES[src.dtype]
+    rp = rows.data_ptr() if rows is not None else None
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream().cuda_stream
+        _native.check(L.gcn_rows_pack_count(dt, src.data_ptr(), src.stride(0), rp, m, F, bits.data_ptr(),
+                                            counts.data_ptr(), st), "gcn_rows_pack_count")
+        torch.cumsum(counts, 0, out=offsets[1:])
+        vals = torch.empty(int(offsets[-1]), dtype=src.dtype, device=dev)
+        _native.check(L.gcn_rows_pack_values(dt, src.data_ptr(), src.stride(0), rp, m, F, offsets.data_ptr(),
+                                             vals.data_ptr(), st), "gcn_rows_pack_values")
+    return bits, offsets, vals
+
+
+def rows_unpack(bits, vals, F):
+    """Inverse of rows_pack on the receiving side: bits int32 [m, F/32] and the non-zero values in
+    row-major order -> dense [m, F] of vals.dtype (C-ABI gcn_bits_row_counts + gcn_rows_unpack; the
+    offsets are the receiver's own scan of the bit counts, no host synchronisation)."""
+    _require_cuda(bits, "bits")
+    _require_cuda(vals, "vals")
+    if (bits.dim() != 2 or bits.dtype != torch.int32 or bits.shape[1] * 32 != F or vals.dim() != 1
+            or vals.dtype not in _DTYPES or vals.device != bits.device):
+        raise RuntimeError(f"rows_unpack: bits {tuple(bits.shape)} {bits.dtype}, vals {tuple(vals.shape)} {vals.dtype}, F {F}")
+    bits, vals = bits.contiguous(), vals.contiguous()
+    m, dev = bits.shape[0], bits.device
+    counts = torch.empty(m, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    out = torch.empty((m, F), dtype=vals.dtype, device=dev)
+    L = _native.lib()
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream().cuda_stream
+        _native.check(L.gcn_bits_row_counts(bits.data_ptr(), m, F // 32, counts.data_ptr(), st), "gcn_bits_row_counts")
+        torch.cumsum(counts, 0, out=offsets[1:])
+        _native.check(L.gcn_rows_unpack(_DTYPES[vals.dtype], bits.data_ptr(), offsets.data_ptr(), vals.data_ptr(),
+                                        m, F, out.data_ptr(), out.stride(0), st), "gcn_rows_unpack")
+    return out
+
+
 def log_softmax_fusable(F, dtype):
     """True when log_softmax over rows of width F can run inside the SpMM's store: the whole row
     must sit in one wavefront (F <= 64, or 16-byte lanes with F / lane width <= 64; a freshly

@@ -142,6 +142,65 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, exchange, build):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _compress_worker(rank, world, port, n, n_edges, out_dir, dtype_name):
+    """ShardedGraph(compress_hidden=True) on the device: the halo rows of the hidden activation
+    travel as bitmask + values through the HIP pack / unpack kernels (gcn_rows_pack_*,
+    gcn_rows_unpack).  The format is lossless, so a training step with dropout must give the SAME
+    BITS as the dense exchange — log-probabilities and every gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pygcn_amd import GCN
+    from pygcn_amd.sharded import ShardedGCN, ShardedGraph
+    import pygcn_amd.spmm as S
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tools.rehearsal import install_host_staging
+    install_host_staging()
+    try:
+        dev = torch.device("cuda:0")
+        dtype = getattr(torch, dtype_name)
+        F = 256 if dtype == torch.float32 else 128
+        x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)).to(dtype)
+        labels = torch.from_numpy(np.random.default_rng(2).integers(0, F, n))
+        results, calls = {}, []
+        real_pack, real_unpack = S.rows_pack, S.rows_unpack
+        import pygcn_amd.sharded as SH
+        SH.rows_pack = lambda *a, **k: (calls.append("pack"), real_pack(*a, **k))[1]
+        SH.rows_unpack = lambda *a, **k: (calls.append("unpack"), real_unpack(*a, **k))[1]
+        for compress in (False, True):
+            sg = ShardedGraph.from_rmat(n, n_edges, rank, world, dev, seed=5, exchange="halo",
+                                        compress_hidden=compress)
+            torch.manual_seed(42)
+            model = GCN(F, F, F, dropout=0.5).to(dev).to(dtype)
+            smodel = ShardedGCN(model, sg)
+            model.train()
+            torch.manual_seed(99)           # (the fused dropout's seed comes from the device generator)
+            logp = smodel(x[sg.r0:sg.r1].to(dev), sg)
+            smodel.nll_loss(logp.float(), labels[sg.r0:sg.r1].to(dev)).backward()
+            smodel.allreduce_grads()
+            results[compress] = (logp.detach().clone(), [p.grad.clone() for p in model.parameters()],
+                                 dict(sg.last_recv_bytes))
+            if compress:
+                dense = sg.halo.n_halo * F * x.element_size()
+                assert 0 < sg.last_recv_bytes["fwd"] < 0.5 * dense      # relu + dropout 0.5: <= 25 % kept
+        assert "pack" in calls and "unpack" in calls                     # the HIP kernels carried it
+        (la, ga, _), (lb, gb, _) = results[False], results[True]
+        assert torch.equal(la, lb), f"rank {rank}: log-probabilities differ"
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b), f"rank {rank}: a gradient differs"
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_compressed_hidden_exchange_same_bits_as_dense(tmp_path, dtype_name):
+    import torch.multiprocessing as mp
+    mp.spawn(_compress_worker, args=(2, _free_port(), 60000, 600000, str(tmp_path), dtype_name),
+             nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 def _bf16_worker(rank, world, port, n, n_edges, out_dir):
     """Config C5's storage (bf16, F = 128) through the sharded path: two ranks on one GPU against
     the single-GPU HIP model on the same bf16 parameters and inputs.  Both run bf16 pipelines with

@@ -1228,3 +1228,52 @@ def test_sddmm_on_the_adjacency_pattern(oracle, dev, F, dtype):
         Gs, Bs = G.to(dev)[:, 1:F - 2], B.to(dev)[:, 1:F - 2]
         ref2 = (G.double().numpy()[row][:, 1:F - 2] * B.double().numpy()[a.col][:, 1:F - 2]).sum(1)
         assert_normwise(sddmm_csr(g, Gs, Bs).cpu(), ref2, 1e-5, "sddmm, unaligned slices")
+
+
+@pytest.mark.parametrize("F,dtype,m", [(256, torch.float32, 5000), (32, torch.float32, 777), (288, torch.float32, 1001),
+                                       (1024, torch.float32, 300), (128, torch.bfloat16, 4099),
+                                       (544, torch.bfloat16, 65), (256, torch.float32, 0)])
+def test_rows_pack_unpack_round_trip(dev, F, dtype, m):
+    """Wire format of the compressed halo exchange (gcn_rows_pack_count / _values, gcn_rows_unpack,
+    gcn_bits_row_counts): bit-exact against the torch-op statement of the same format
+    (pygcn_amd.sharded.pack_bits) and a bit-exact round trip, with a row list, a padded leading
+    dimension, -0.0 (travels as zero), NaN / inf (travel as values) and all-zero / full rows."""
+    from pygcn_amd.sharded import pack_bits
+    from pygcn_amd.spmm import rows_pack, rows_unpack
+    g = torch.Generator(device="cpu").manual_seed(F + m)
+    n = 2 * m + 3
+    wide = torch.zeros((n, F + 8), dtype=dtype, device=dev)
+    src = wide[:, :F]                                            # leading dimension F + 8
+    vals = torch.randn((n, F), generator=g) * (torch.rand((n, F), generator=g) < 0.3)
+    vals[0].zero_()
+    vals[1] = 1.0
+    vals[2, ::3] = -0.0
+    vals[2, 1] = float("nan")
+    vals[2, 4] = float("inf")
+    src.copy_(vals.to(dtype))
+    for rows in (None, torch.randperm(n, generator=g)[:m].to(dev)):
+        want = src if rows is None else src[rows]
+        bits, offsets, packed = rows_pack(src, rows)
+        mask = want != 0
+        assert torch.equal(bits, pack_bits(mask))
+        assert torch.equal(offsets[1:], mask.sum(1).cumsum(0)) and int(offsets[0]) == 0
+        ref_vals = want[mask]
+        assert packed.dtype == dtype and packed.shape == ref_vals.shape
+        assert torch.equal(packed.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                           ref_vals.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+        back = rows_unpack(bits, packed, F)
+        expect = torch.where(mask, want, torch.zeros_like(want))  # (-0.0 arrives as +0.0)
+        it = torch.int16 if dtype == torch.bfloat16 else torch.int32
+        assert back.shape == expect.shape and torch.equal(back.contiguous().view(it), expect.contiguous().view(it))
+
+
+def test_rows_pack_rejects_unsupported_shapes(dev):
+    from pygcn_amd.spmm import rows_pack, rows_unpack
+    with pytest.raises(RuntimeError):
+        rows_pack(torch.zeros((4, 48), device=dev))              # width not a multiple of 32
+    with pytest.raises(RuntimeError):
+        rows_pack(torch.zeros((4, 64), device=dev, dtype=torch.float16))
+    with pytest.raises(RuntimeError):
+        rows_pack(torch.zeros((4, 64)))                          # host tensor: no CPU path
+    with pytest.raises(RuntimeError):
+        rows_unpack(torch.zeros((4, 2), dtype=torch.int32, device=dev), torch.zeros(0, device=dev), 96)
