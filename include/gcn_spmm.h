@@ -395,7 +395,8 @@ typedef struct gcn_gemm_epilogue {
      * mask_scale : 0 — the backward of a fused ReLU / dropout epilogue (out > 0 encodes ReLU and
      * keep, scale = 1 / (1 - p)) applied to the grad_input GEMM in its own store. */
     const float *mask_src;    /* DEVICE [*, N] in the GEMM's storage type — fp32 for gcn_gemm_xw256_f32_h2, bf16
-                               * (passed through this pointer) for gcn_gemm_xw_bf16 — leading dimension ld_mask, or NULL */
+                               * (passed through this pointer) for gcn_gemm_xw_bf16 — leading dimension ld_mask, or NULL;
+                               * rows 16-byte aligned (GCN_E_ALIGN) */
     int64_t ld_mask;
     float mask_scale;
     /* optional DEVICE int32 list [M]: output row r reads mask row mask_rows[r]; NULL = the input

@@ -478,6 +478,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned char *wimg = ws + kH2HeaderBytes;
     const int64_t n_tiles = (M + kTileRows - 1) / kTileRows;
+    // Forward epilogue: the bias and the device-resident seed are read ONCE here, the bias into LDS.
+    // Read where they are used (in the store section) they compile to vector loads — per-lane
+    // addresses after the half-wave select — and a vector load that is consumed at once is waited
+    // for with `s_waitcnt vmcnt(0)`: loads and stores retire in order on one counter, so every one
+    // of the 32 column groups of a tile drained all earlier stores AND the next tile's prefetch
+    // (what held this instantiation at 0.45 of HBM against 0.54 for the plain product).
+    __shared__ __attribute__((aligned(16))) float bias_lds[FWD_EPI ? kN : 4];
+    uint32_t seed_k0 = ep.seed_lo, seed_k1 = ep.seed_hi;
+    if (FWD_EPI) {
+        if (ep.bias != nullptr && tid < kN) bias_lds[tid] = ep.bias[tid];
+        if (ep.seed_dev != nullptr) {
+            const uint64_t sd = *ep.seed_dev;
+            seed_k0 = (uint32_t)sd;
+            seed_k1 = (uint32_t)(sd >> 32);
+        }
+        __syncthreads();
+    }
 
     // scales (wave-uniform scalars)
     int x_exp = 14 - floor_log2f(*x_bound);
@@ -759,12 +776,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 // column blocks, not between the chains
                 uint32_t r8[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
                 if (FWD_EPI && ep.drop_thresh != 0u) {                        // (uniform branch)
-                    uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
-                    if (ep.seed_dev != nullptr) {
-                        const uint64_t sd = *ep.seed_dev;
-                        k0 = (uint32_t)sd;
-                        k1 = (uint32_t)(sd >> 32);
-                    }
+                    const uint32_t k0 = seed_k0, k1 = seed_k1;
                     const int64_t drow = row + ep.drop_row_base;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -796,14 +808,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     // ((Â·X)·W + b, pygcn/layers.py:33-36 reassociated): bias, ReLU, inverted dropout
                     const int f = 32 * nb + 8 * g + 4 * (lane >> 5);          // first of 4 columns
                     if (FWD_EPI && bias_p != nullptr) {
-                        // the 8 bias values of this column group through the SCALAR cache (uniform
-                        // address), the lane half picks its 4: no per-lane addresses to keep alive
-                        const float *bq = bias_p + 32 * nb + 8 * g;
-                        const bool hi = (lane >> 5) != 0;
-                        v.x += hi ? bq[4] : bq[0];
-                        v.y += hi ? bq[5] : bq[1];
-                        v.z += hi ? bq[6] : bq[2];
-                        v.w += hi ? bq[7] : bq[3];
+                        // this lane's 4 bias values from LDS (a broadcast read: lgkmcnt, not vmcnt)
+                        const f32x4 b4 = *(const f32x4 *)(bias_lds + f);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                     }
                     if (FWD_EPI && ep.relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
@@ -869,37 +876,105 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 // the W load), the X fragments of the NEXT tile are in flight while the current one is multiplied
 // and stored, and the bf16 output rows leave as 16-byte stores (the two half-waves exchange their
 // 4-column groups with v_permlane32_swap first).
-template <int K, int N, bool FWD_EPI>
-__global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf16_kernel(const uint16_t *__restrict__ X, int64_t ldx,
-                                                        const uint16_t *__restrict__ wimg,
-                                                        uint16_t *__restrict__ Y, int64_t ldy,
-                                                        int64_t M, int64_t n_tiles, const H2Epi ep)
+// EPI: 0 plain product, 1 forward epilogue (bias / ReLU / dropout), 2 backward mask read at the
+// output row, 3 backward mask read through a row list.
+//
+// NO DATA-DEPENDENT BRANCH AROUND A MEMORY INSTRUCTION inside the tile loop: the X fragments and the
+// Y rows move through BUFFER instructions whose descriptor covers exactly the rows of the tile that
+// exist (hardware range check: reads past the end give zeros, writes are dropped; a tile past the
+// last one has zero records), and the loop runs tiles in pairs with the two fragment register sets
+// swapped instead of copied.  Both matter for the prefetch: hipcc's wait-count pass merges
+// the pending-operation state of the branches of an `if` pessimistically, and placed each copy
+// `a_cur[c] = a_nxt[c]` right after the last MFMA reading a_cur[c] — either way the wave waited
+// (`s_waitcnt vmcnt(7 - c)`) on loads issued a few instructions earlier and the "prefetch" hid
+// nothing (0.40 of HBM at C5).  The mask of the backward form is requested BEFORE the next tile's
+// fragments (loads retire in order: a wait on the mask must not drain the prefetch), its row-list
+// entry one tile ahead.
+template <int K, int N, int EPI>
+__global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) : 2)) void gemm_bf16_kernel(
+    const uint16_t *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ wimg,
+    uint16_t *__restrict__ Y, int64_t ldy, int64_t M, int64_t n_tiles, const H2Epi ep)
 {
     constexpr int KC = K / 16, NB = N / 32;
+    constexpr bool FWD_EPI = EPI == 1, MASK = EPI >= 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];    // K * N * 2 bytes
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         const u32x4 *src = (const u32x4 *)wimg;
         u32x4 *dst = (u32x4 *)wlds;
         for (int i = tid; i < K * N * 2 / 16; i += 256) dst[i] = src[i];
     }
+    // (forward epilogue: bias into LDS, device-resident seed read once — in the store section they
+    //  would be vector loads waited for with vmcnt(0), see gemm_xw256_h2_kernel)
+    __shared__ __attribute__((aligned(16))) float bias_lds[FWD_EPI ? N : 4];
+    uint32_t seed_k0 = ep.seed_lo, seed_k1 = ep.seed_hi;
+    if (FWD_EPI) {
+        if (ep.bias != nullptr && tid < N) bias_lds[tid] = ep.bias[tid];
+        if (ep.seed_dev != nullptr) {
+            const uint64_t sd = *ep.seed_dev;
+            seed_k0 = (uint32_t)sd;
+            seed_k1 = (uint32_t)(sd >> 32);
+        }
+    }
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * 4;
-    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;                  // (wave-uniform: scalar registers)
     if (t >= n_tiles) return;
     const int r = lane & 31, h = lane >> 5;
-    u32x4 a_cur[KC], a_nxt[KC];
-    auto fetch = [&](int64_t tile, u32x4 (&dst)[KC]) {
-        int64_t row = tile * 32 + r;
-        row = row < M ? row : M - 1;                        // (clamped: the store is masked)
-        const u32x4 *p = (const u32x4 *)(X + row * ldx + 8 * h);
-#pragma unroll
-        for (int c = 0; c < KC; ++c) dst[c] = p[2 * c];    // k = 16c + 8h .. +8
+    const uint32_t ldx_b = (uint32_t)ldx * 2u, ldy_b = (uint32_t)ldy * 2u;   // (host: 32 rows < 2 GiB)
+    // descriptor of the rows of tile `tile` that exist, `width_b` bytes used per row
+    auto tile_rsrc = [&](const uint16_t *base, int64_t ld, uint32_t ld_b, int64_t tile, uint32_t width_b) {
+        const int64_t left = M - tile * 32;
+        const uint32_t rows = left >= 32 ? 32u : (left > 0 ? (uint32_t)left : 0u);
+        const uint64_t p = (uint64_t)(base + (rows ? tile : 0) * 32 * ld);
+        // (all wave-uniform; said so explicitly — a descriptor word the compiler keeps in a vector
+        //  register turns every access into a per-lane "waterfall" loop)
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+        const uint32_t nrec = __builtin_amdgcn_readfirstlane(rows ? (rows - 1u) * ld_b + width_b : 0u);
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, nrec, 0x00020000);
     };
-    fetch(t, a_cur);
-    for (; t < n_tiles; t += stride) {
-        const bool more = t + stride < n_tiles;
-        if (more) fetch(t + stride, a_nxt);
+    auto fetch = [&](int64_t tile, u32x4 (&dst)[KC]) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(X, ldx, ldx_b, tile, K * 2);
+        const uint32_t voff = (uint32_t)r * ldx_b + 16u * h;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)                             // k = 16c + 8h .. +8
+            dst[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 32 * c, 0, 0));
+    };
+    // (mask variants) the row of the mask that belongs to output row `row` of tile `tile`
+    // (EPI 3: the raw 32-bit list entry — widened where it is used, one tile later; a conversion
+    //  at the load would be scheduled right behind it and wait for it there)
+    auto mask_index = [&](int64_t tile) -> int32_t {
+        int64_t row = tile * 32 + r;
+        row = row < M ? row : M - 1;                             // (clamped: the store is dropped)
+        return EPI == 3 ? ep.mask_rows[row] : 0;
+    };
+    u32x4 a0[KC], a1[KC];
+    int32_t m0 = 0, m1 = 0;
+    auto one_tile = [&](const int64_t t, u32x4 (&a_cur)[KC], u32x4 (&a_nxt)[KC], const int32_t m_cur, int32_t &m_nxt) {
+        // this lane's 8 stored columns of every (nb, g pair): 16 bytes of the mask each
+        u32x4 mk[NB][2];
+        if (MASK) {
+            // (scheduling fences around the mask requests: nothing of this tile — the widening of
+            //  m_cur, the swaps of the mask words in the store section — may move to where it would
+            //  wait on a load that is younger than the prefetch)
+            __builtin_amdgcn_sched_barrier(0);
+            int32_t mc = m_cur;
+            asm volatile("" : "+v"(mc));         // (the list entry is first LOOKED AT here, one tile after its load)
+            int64_t mi = t * 32 + r;
+            mi = EPI == 3 ? (int64_t)mc : (mi < M ? mi : M - 1);
+            const unsigned char *mrow = (const unsigned char *)((const uint16_t *)ep.mask_src + mi * ep.ld_mask) + 16 * h;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) mk[nb][q] = *(const u32x4 *)(mrow + (32 * nb + 16 * q) * 2);
+            // (the order matters and the scheduler does not know it: loads retire in order, so a
+            //  mask requested AFTER the prefetch could only be waited for by draining the prefetch)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fetch(t + stride, a_nxt);
+        if (MASK) m_nxt = mask_index(t + stride < n_tiles ? t + stride : t);
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -920,93 +995,101 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? 3 : 2)) void gemm_bf
                 acc[nb] = mfma(b, a_cur[c], acc[nb]);      // transposed tile: lane = output row
             }
         }
+        if (MASK) __builtin_amdgcn_sched_barrier(0);
         const int64_t row = t * 32 + r;
-        if (row < M) {
-            unsigned char *yrow = (unsigned char *)(Y + row * ldy) + (h ? 16 : 0);
-            const uint16_t *mrow = (!FWD_EPI && ep.mask_src != nullptr)
-                ? (const uint16_t *)ep.mask_src + (ep.mask_rows ? (int64_t)ep.mask_rows[row] : row) * ep.ld_mask
-                : nullptr;
+        const __amdgpu_buffer_rsrc_t ys = tile_rsrc(Y, ldy, ldy_b, t, N * 2);
+        const uint32_t yoff = (uint32_t)r * ldy_b + 16u * h;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    if (FWD_EPI) {
-                        // the layer's forward epilogue on the fp32 accumulators (the layer evaluated
-                        // as (Â·X)·W + b, its last stage being this GEMM): bias, ReLU, Philox
-                        // dropout — the keep function of gcn_spmm.hip, one Philox call per 8 columns
-                        uint32_t r4[4] = {0u, 0u, 0u, 0u};
+            for (int g = 0; g < 4; g += 2) {
+                if (FWD_EPI) {
+                    // the layer's forward epilogue on the fp32 accumulators (the layer evaluated
+                    // as (Â·X)·W + b, its last stage being this GEMM): bias, ReLU, Philox
+                    // dropout — the keep function of gcn_spmm.hip, one Philox call per 8 columns
+                    uint32_t r4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int gg = g; gg < g + 2; ++gg) {
-                            const int f = 32 * nb + 8 * gg + 4 * h;                // first of 4 columns
-                            float v[4] = {acc[nb][4 * gg], acc[nb][4 * gg + 1], acc[nb][4 * gg + 2],
-                                          acc[nb][4 * gg + 3]};
-                            if (ep.bias != nullptr) {
-                                const float *bq = ep.bias + 32 * nb + 8 * gg;     // (scalar loads)
-                                v[0] += h ? bq[4] : bq[0];
-                                v[1] += h ? bq[5] : bq[1];
-                                v[2] += h ? bq[6] : bq[2];
-                                v[3] += h ? bq[7] : bq[3];
-                            }
-                            if (ep.relu) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                            }
-                            if (ep.drop_thresh != 0u) {                            // (uniform branch)
-                                if (gg == g) {       // one call for the pair of groups g, g + 1
-                                    uint32_t k0 = ep.seed_lo, k1 = ep.seed_hi;
-                                    if (ep.seed_dev != nullptr) {
-                                        const uint64_t sd = *ep.seed_dev;
-                                        k0 = (uint32_t)sd;
-                                        k1 = (uint32_t)(sd >> 32);
-                                    }
-                                    uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)h;
-                                    asm volatile("" : "+v"(cw));       // (no hoisting of the first round)
-                                    const int64_t drow = row + ep.drop_row_base;
-                                    h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r4);
-                                }
-                                const uint32_t w0 = (gg & 1) ? r4[2] : r4[0], w1 = (gg & 1) ? r4[3] : r4[1];
-                                v[0] = (w0 & 0xFFFFu) >= ep.drop_thresh ? v[0] * ep.drop_scale : 0.f;
-                                v[1] = (w0 >> 16) >= ep.drop_thresh ? v[1] * ep.drop_scale : 0.f;
-                                v[2] = (w1 & 0xFFFFu) >= ep.drop_thresh ? v[2] * ep.drop_scale : 0.f;
-                                v[3] = (w1 >> 16) >= ep.drop_thresh ? v[3] * ep.drop_scale : 0.f;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[nb][4 * gg + j] = v[j];
+                    for (int gg = g; gg < g + 2; ++gg) {
+                        float v[4] = {acc[nb][4 * gg], acc[nb][4 * gg + 1], acc[nb][4 * gg + 2],
+                                      acc[nb][4 * gg + 3]};
+                        if (ep.bias != nullptr) {
+                            const f32x4 b4 = *(const f32x4 *)(bias_lds + 32 * nb + 8 * gg + 4 * h);
+                            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                         }
-                    }
-                    if (!FWD_EPI && ep.mask_src != nullptr) {              // (uniform branch)
-                        // backward of a fused ReLU / dropout epilogue in the grad_input GEMM's own
-                        // store: y = mask > 0 ? y * scale : 0, the mask (bf16 activations of the
-                        // layer below) read at this lane's 4 columns of each group through the row
-                        // list — no compacting copy of the mask rows, no extra elementwise pass
+                        if (ep.relu) {
 #pragma unroll
-                        for (int gg = g; gg < g + 2; ++gg) {
-                            const uint2 mk = *(const uint2 *)(mrow + 32 * nb + 8 * gg + 4 * h);
-                            const uint32_t mb[4] = {mk.x << 16, mk.x & 0xffff0000u, mk.y << 16, mk.y & 0xffff0000u};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                acc[nb][4 * gg + j] = __uint_as_float(mb[j]) > 0.f ? acc[nb][4 * gg + j] * ep.mask_scale : 0.f;
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         }
+                        if (ep.drop_thresh != 0u) {                            // (uniform branch)
+                            if (gg == g) {       // one call for the pair of groups g, g + 1
+                                const uint32_t k0 = seed_k0, k1 = seed_k1;
+                                uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)h;
+                                asm volatile("" : "+v"(cw));       // (no hoisting of the first round)
+                                const int64_t drow = row + ep.drop_row_base;
+                                h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r4);
+                            }
+                            const uint32_t w0 = (gg & 1) ? r4[2] : r4[0], w1 = (gg & 1) ? r4[3] : r4[1];
+                            v[0] = (w0 & 0xFFFFu) >= ep.drop_thresh ? v[0] * ep.drop_scale : 0.f;
+                            v[1] = (w0 >> 16) >= ep.drop_thresh ? v[1] * ep.drop_scale : 0.f;
+                            v[2] = (w1 & 0xFFFFu) >= ep.drop_thresh ? v[2] * ep.drop_scale : 0.f;
+                            v[3] = (w1 >> 16) >= ep.drop_thresh ? v[3] * ep.drop_scale : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[nb][4 * gg + j] = v[j];
                     }
-                    // groups k = 4nb + g and k + 1: this lane's 4 columns of each, packed to bf16
-                    f32x2 p0 = {acc[nb][4 * g], acc[nb][4 * g + 1]}, p1 = {acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
-                    f32x2 q0 = {acc[nb][4 * g + 4], acc[nb][4 * g + 5]}, q1 = {acc[nb][4 * g + 6], acc[nb][4 * g + 7]};
-                    uint32_t ax = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
-                    uint32_t ay = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
-                    uint32_t bx = __builtin_bit_cast(uint32_t, __builtin_convertvector(q0, bf16x2));
-                    uint32_t by = __builtin_bit_cast(uint32_t, __builtin_convertvector(q1, bf16x2));
-                    auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                    auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                    // lower half-wave: columns 8k .. 8k+7, upper: 8k+8 .. 8k+15 (16 bytes each)
-                    const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-                    *(u32x4 *)(yrow + (32 * nb + 8 * g) * 2) = v;
                 }
+                // groups k = 4nb + g and k + 1: this lane's 4 columns of each, packed to bf16
+                f32x2 p0 = {acc[nb][4 * g], acc[nb][4 * g + 1]}, p1 = {acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+                f32x2 q0 = {acc[nb][4 * g + 4], acc[nb][4 * g + 5]}, q1 = {acc[nb][4 * g + 6], acc[nb][4 * g + 7]};
+                if (MASK) {
+                    // backward of a fused ReLU / dropout epilogue in the grad_input GEMM's own
+                    // store: y = mask > 0 ? y * scale : 0 on the fp32 accumulators, before the
+                    // rounding.  The mask words were fetched in STORE layout (8 consecutive columns
+                    // per lane); the accumulators are still in MFMA layout (4 + 4 columns, the
+                    // other half-wave holding the columns in between), so the mask words take the
+                    // inverse of the swap the packed results take below.
+                    const u32x4 m = mk[nb][g >> 1];
+                    auto ux = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
+                    auto uy = __builtin_amdgcn_permlane32_swap(m[1], m[3], false, false);
+                    const uint32_t mw[4] = {ux[0], uy[0], ux[1], uy[1]};     // columns of p0, p1, q0, q1
+                    auto keep = [&](f32x2 &v, uint32_t w) {
+                        v.x = __uint_as_float(w << 16) > 0.f ? v.x * ep.mask_scale : 0.f;
+                        v.y = __uint_as_float(w & 0xffff0000u) > 0.f ? v.y * ep.mask_scale : 0.f;
+                    };
+                    keep(p0, mw[0]);
+                    keep(p1, mw[1]);
+                    keep(q0, mw[2]);
+                    keep(q1, mw[3]);
+                }
+                uint32_t ax = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+                uint32_t ay = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                uint32_t bx = __builtin_bit_cast(uint32_t, __builtin_convertvector(q0, bf16x2));
+                uint32_t by = __builtin_bit_cast(uint32_t, __builtin_convertvector(q1, bf16x2));
+                auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                // lower half-wave: columns 8k .. 8k+7, upper: 8k+8 .. 8k+15 (16 bytes each)
+                const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v),
+                                                       ys, yoff + (32 * nb + 8 * g) * 2, 0, 0);
             }
         }
-        if (more) {
+    };
+    fetch(t, a0);
+    if (MASK) m0 = mask_index(t);
+    {
+        // NB x 2 stores into a zero-record descriptor (dropped by the range check): the loop's first
+        // pass then sees the same sequence of pending memory operations as every later one
+        // (fragments, a tile's stores, next fragments), and the counted waits hipcc places in the
+        // loop are those of the steady state instead of the minimum over the loop's two entries —
+        // which made every tile wait for the previous tile's stores before its first MFMA
+        const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, 0, 0x00020000);
+        const __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int z = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int c = 0; c < KC; ++c) a_cur[c] = a_nxt[c];
-        }
+        for (int i = 0; i < NB * 2; ++i) __builtin_amdgcn_raw_buffer_store_b128(z, none, 16 * i, 0, 0);
+    }
+    for (; t < n_tiles; t += 2 * stride) {
+        one_tile(t, a0, a1, m0, m1);
+        one_tile(t + stride, a1, a0, m1, m0);      // (past the last tile: zero records, a no-op)
     }
 }
 
@@ -1466,8 +1549,8 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
         if (epi->mask_src != nullptr) {
             if (epi->bias != nullptr || epi->relu || epi->dropout_p > 0.f)
                 return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: forward epilogue and backward mask exclude each other");
-            if (((uintptr_t)epi->mask_src) % 8 != 0 || epi->ld_mask % 4 != 0 || epi->ld_mask < N)
-                return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: mask rows must be 8-byte aligned bf16 [*, N]");
+            if (((uintptr_t)epi->mask_src) % 16 != 0 || epi->ld_mask % 8 != 0 || epi->ld_mask < N)
+                return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: mask rows must be 16-byte aligned bf16 [*, N]");
             ep.mask_src = (const float *)epi->mask_src;      // (bf16 data; typed per kernel)
             ep.ld_mask = epi->ld_mask;
             ep.mask_rows = epi->mask_rows;
@@ -1498,27 +1581,38 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
     if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 8) != 0 ||
         (ldy % 8) != 0)
         return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw_bf16: X / Y rows must be 16-byte aligned");
+    if (ldx > (1 << 24) || ldy > (1 << 24))      // (32 rows of a tile sit under one 32-bit buffer offset)
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw_bf16: leading dimensions above 2^24 are not supported");
     hipStream_t s = (hipStream_t)stream;
     const int frags = (int)((K / 16) * (N / 32) * 64);
     hipLaunchKernelGGL(order_w_bf16_kernel, dim3((frags + 255) / 256), dim3(256), 0, s,
                        (const uint16_t *)W, ldw, (uint16_t *)workspace, (int)K, (int)N);
     const int64_t tiles = (M + 31) / 32;
-    // resident workgroups per CU: LDS (160 KiB / image) and registers allow 3 (128 x 128) … 1
-    const int per_cu = need <= 32 * 1024 ? 3 : (need <= 64 * 1024 ? 2 : 1);
-    const unsigned grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, (int64_t)256 * per_cu);
+    // a PERSISTENT grid: exactly the workgroups that are resident together on the 256 CUs (LDS image
+    // and the instantiation's registers decide: 3 per CU at 128 x 128 … 1), asked of the runtime once
 #define GCN_LAUNCH_BF16_E(KK, NN, EE)                                                               \
     do {                                                                                            \
+        static int per_cu = 0;                                                                      \
         hipError_t ae = hipFuncSetAttribute((const void *)gemm_bf16_kernel<KK, NN, EE>,            \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)need); \
         if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw_bf16: LDS size"); \
+        if (per_cu == 0) {                                                                          \
+            int nb = 0;                                                                             \
+            ae = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_bf16_kernel<KK, NN, EE>, 256, need); \
+            if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw_bf16: occupancy"); \
+            per_cu = nb > 0 ? nb : 1;                                                               \
+        }                                                                                           \
+        const unsigned grid = (unsigned)std::min<int64_t>((tiles + 3) / 4, (int64_t)256 * per_cu); \
         hipLaunchKernelGGL((gemm_bf16_kernel<KK, NN, EE>), dim3(grid), dim3(256), need, s,          \
                            (const uint16_t *)X, ldx, (const uint16_t *)workspace, (uint16_t *)Y,   \
                            ldy, M, tiles, ep);                                                      \
     } while (0)
 #define GCN_LAUNCH_BF16(KK, NN)                                                                     \
     do {                                                                                            \
-        if (fwd) GCN_LAUNCH_BF16_E(KK, NN, true);                                                   \
-        else GCN_LAUNCH_BF16_E(KK, NN, false);                                                      \
+        if (fwd) GCN_LAUNCH_BF16_E(KK, NN, 1);                                                      \
+        else if (ep.mask_src == nullptr) GCN_LAUNCH_BF16_E(KK, NN, 0);                              \
+        else if (ep.mask_rows == nullptr) GCN_LAUNCH_BF16_E(KK, NN, 2);                             \
+        else GCN_LAUNCH_BF16_E(KK, NN, 3);                                                          \
     } while (0)
     if (K == 128 && N == 128) GCN_LAUNCH_BF16(128, 128);
     else if (K == 128 && N == 256) GCN_LAUNCH_BF16(128, 256);

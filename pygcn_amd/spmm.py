@@ -578,7 +578,7 @@ def gemm_bf16(X, W, bias=None, relu=False, dropout_p=0.0, seed=0, row_base=0, ma
     if mask_src is not None:
         if (bias is not None or relu or dropout_p > 0.0 or mask_src.dtype != torch.bfloat16
                 or mask_src.dim() != 2 or mask_src.shape[1] != N or mask_src.stride(1) != 1
-                or mask_src.stride(0) % 4 or mask_src.data_ptr() % 8 or mask_src.device != X.device):
+                or mask_src.stride(0) % 8 or mask_src.data_ptr() % 16 or mask_src.device != X.device):
             return None
         if mask_rows is not None and (mask_rows.dtype != torch.int32 or not mask_rows.is_contiguous()
                                       or mask_rows.device != X.device or mask_rows.numel() < X.shape[0]):

@@ -192,7 +192,37 @@ int main()
                 err_gp, scale_gp, err_cs, scale_cs, amax, want_amax);
     const bool ok22 = err_lse <= 1e-5 && err_gp <= 1e-5 * scale_gp && err_cs <= 2e-5 * scale_cs + 1e-9 &&
                       amax == want_amax;
-    const bool ok = ok22 && err <= 1e-5 * scale && err_t <= 1e-5 * scale_t && bad == GCN_E_BADARG && plan.n_chunks > 0;
+    // ---- rows as bitmask + non-zero values (wire format of the compressed halo exchange): round trip
+    const int64_t pm = 37, pF = 64;
+    std::vector<float> dense(pm * pF, 0.f), back(pm * pF, -1.f);
+    std::vector<int64_t> offs(pm + 1, 0);
+    for (int64_t i = 0; i < pm * pF; ++i) dense[i] = (i * 2654435761u % 7 < 2) ? (float)(i % 11) - 5.5f : 0.f;
+    float *d_dense = to_dev(dense), *d_back = nullptr, *d_pv = nullptr;
+    uint32_t *d_bits = nullptr;
+    int32_t *d_cnt = nullptr;
+    HIP_OK(hipMalloc((void **)&d_back, pm * pF * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_pv, pm * pF * sizeof(float)));
+    HIP_OK(hipMalloc((void **)&d_bits, pm * (pF / 32) * sizeof(uint32_t)));
+    HIP_OK(hipMalloc((void **)&d_cnt, pm * sizeof(int32_t)));
+    GCN_OK(gcn_rows_pack_count(GCN_DTYPE_F32, d_dense, pF, nullptr, pm, pF, d_bits, d_cnt, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<int32_t> cnt(pm), cnt2(pm);
+    HIP_OK(hipMemcpy(cnt.data(), d_cnt, pm * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < pm; ++r) offs[r + 1] = offs[r] + cnt[r];          // the caller's scan
+    int64_t *d_offs = to_dev(offs);
+    GCN_OK(gcn_rows_pack_values(GCN_DTYPE_F32, d_dense, pF, nullptr, pm, pF, d_offs, d_pv, stream));
+    GCN_OK(gcn_bits_row_counts(d_bits, pm, pF / 32, d_cnt, stream));
+    GCN_OK(gcn_rows_unpack(GCN_DTYPE_F32, d_bits, d_offs, d_pv, pm, pF, d_back, pF, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(back.data(), d_back, back.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(cnt2.data(), d_cnt, pm * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t nz = 0;
+    for (float v : dense) nz += v != 0.f;
+    const bool ok_pack = back == dense && cnt2 == cnt && offs[pm] == nz &&
+                         gcn_rows_pack_count(GCN_DTYPE_F32, d_dense, pF, nullptr, pm, 48, d_bits, d_cnt, stream) == GCN_E_BADARG;
+    std::printf("C_ABI_SMOKE pack nonzeros=%lld of %lld round_trip=%s\n", (long long)offs[pm], (long long)(pm * pF),
+                ok_pack ? "exact" : "MISMATCH");
+    const bool ok = ok22 && ok_pack && err <= 1e-5 * scale && err_t <= 1e-5 * scale_t && bad == GCN_E_BADARG && plan.n_chunks > 0;
     std::printf(ok ? "C_ABI_SMOKE OK\n" : "C_ABI_SMOKE FAILED\n");
     return ok ? 0 : 5;
 }

@@ -1,4 +1,5 @@
-"""Time of the grad_input GEMM with the ReLU / dropout backward mask in its store (M = 10^7)."""
+"""Times of the fp32 256 -> 256 GEMM (gcn_gemm_xw256_f32_h2) at M = 10^7: plain, with the layer's
+forward epilogue (bias + ReLU + dropout) and with the ReLU / dropout backward mask in its store."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from pygcn_amd.spmm import gemm_xw256
@@ -17,6 +18,11 @@ def t(fn, reps=5):
 Y = gemm_xw256(X, W, x_bound=b, mask_src=H, mask_scale=2.0)
 ref = torch.where(H[:4096] > 0, (X[:4096].double() @ W.double()) * 2.0, torch.zeros((), dtype=torch.float64, device=dev))
 print("masked normwise err %.3e" % ((Y[:4096].double() - ref).abs().max() / ref.abs().max()).item())
+bias = torch.randn(256, device=dev) * 0.1
+gb = M * 256 * 4 / 1e9
 for rnd in range(3):
-    print("round %d  plain %.2f ms   masked %.2f ms" % (rnd, t(lambda: gemm_xw256(X, W, x_bound=b)),
-                                                        t(lambda: gemm_xw256(X, W, x_bound=b, mask_src=H, mask_scale=2.0))), flush=True)
+    a = t(lambda: gemm_xw256(X, W, x_bound=b))
+    f = t(lambda: gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.5, seed=1234))
+    m = t(lambda: gemm_xw256(X, W, x_bound=b, mask_src=H, mask_scale=2.0))
+    print("round %d  plain %.2f ms (%.2f)   forward %.2f ms (%.2f)   masked %.2f ms (%.2f)   [fraction of 8 TB/s]"
+          % (rnd, a, 2 * gb / a / 8, f, 2 * gb / f / 8, m, 3 * gb / m / 8), flush=True)
