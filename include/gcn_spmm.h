@@ -436,7 +436,8 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
  * multiple of 16 entries with valid indices (n_list counts the real ones).  Scaled two-part fp16
  * scheme as gcn_gemm_xw256_f32_h2 (a_absmax_bound / g_absmax_bound: DEVICE floats, upper bounds
  * of max|A|, max|G| over the listed rows); partial products of row slabs are added in slab order
- * (deterministic).  Workspace >= gcn_gemm_atg256_workspace_bytes(n_list).
+ * (deterministic).  Rows of A and G 16-byte aligned (GCN_E_ALIGN).  Workspace >=
+ * gcn_gemm_atg256_workspace_bytes(n_list).
  */
 size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list);
 int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,

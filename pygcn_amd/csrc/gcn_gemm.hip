@@ -1115,40 +1115,47 @@ __global__ __launch_bounds__(256) void order_w_bf16_kernel(const uint16_t *__res
 //
 // The reduction runs over the graph's vertices, so both operands are "k-major" for the MFMA: a
 // lane needs 8 consecutive ROWS of one column.  No transpose through LDS is needed: a wave loads
-// 64 consecutive columns of ONE row per instruction (256 contiguous bytes, row address on the
-// scalar unit — which makes the row GATHER free: ra / rg list the rows on which the gradient can
-// be non-zero, pygcn_amd/fused.py), 16 rows per step; register j then holds row j and register
-// 8+j row 8+j of columns [0,32 | 32,64), and ONE v_permlane32_swap per pair turns them into the
-// two 32-column MFMA fragments (lanes < 32: k = j, lanes >= 32: k = 8 + j).  Waves 0-3 load, split
-// and publish the A fragments (64 columns each), waves 4-7 the G fragments (LDS, double-buffered,
-// one barrier per step); every wave then multiplies its 64 x 128 block of the result (2 x 4 tiles).
-// Loads run kAtgDepth steps ahead in a register ring.  The row list is cut into slabs, one per
-// workgroup; the slabs' partial products are added in slab order by a second kernel
+// ONE WHOLE ROW per instruction — 256 floats = 1 KiB, 16 bytes per lane, row address on the scalar
+// unit, which makes the row GATHER free (ra / rg list the rows on which the gradient can be
+// non-zero, pygcn_amd/fused.py) — and 8 consecutive list entries per SUPER-STEP of 32 rows: lane l
+// then holds k = 0..7 of its four columns 4l..4l+3, i.e. one complete 16-byte MFMA fragment for
+// each of four 32-column tiles
+//         tile T = 2q + (l >> 5), fragment lane (l & 31) + 32·(k-half),  column 128·(T & 1) + 4·(l & 31) + (T >> 1)
+// — a permutation of the columns that only decides where a result element is stored.  Waves 0-3
+// load, split into (h, m) fp16 parts and publish the A fragments (8 rows of the super-step each),
+// waves 4-7 the G fragments (LDS, double-buffered, ONE barrier per 32 rows); every wave then
+// multiplies its 64 x 128 block of the result (2 x 4 tiles) over the super-step's two MFMA steps.
+// (Round 3, first form: 64 columns of one row per instruction, 4 bytes per lane.  The address unit
+//  takes as long for such a wave instruction as for a 16-byte one, all waves issue their loads at
+//  the same point of the step, and the ablation builds showed load phase and arithmetic adding up
+//  instead of overlapping: 5.5 ms = 2.9 ms without loads + 2.6 ms — tools/atg_variant_sweep.py.)
+// Loads run kAtgDepth super-steps ahead in a register ring.  The row list is cut into slabs, one
+// per workgroup; the slabs' partial products are added in slab order by a second kernel
 // (deterministic, no atomics).  Index lists are padded to a multiple of 16 entries with valid
-// indices (n_list counts the real entries): the 16 indices of a step are one scalar load.
-constexpr int kAtgStepsMin = 8;                 // at least this many 16-row steps per workgroup
+// indices (n_list counts the real entries): the 8 indices of a wave's share are one scalar load.
+constexpr int kAtgSuperMin = 4;                 // at least this many 32-row super-steps per workgroup
 constexpr int kAtgMaxWgs = 256;
-constexpr int kAtgDepth = 3;
+constexpr int kAtgDepth = 2;
+constexpr int kAtgBufBytes = 2 * 2 * 8 * 2 * kFragBytes;   // [operand][MFMA step][tile][split] = 64 KiB
 
 __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
     const float *__restrict__ G, int64_t ldg, const int32_t *__restrict__ rg, int64_t n_list,
     const float *__restrict__ a_bound, const float *__restrict__ g_bound,
-    float *__restrict__ partial, int64_t steps_per_wg)
+    float *__restrict__ partial, int64_t supers_per_wg)
 {
-    // [buffer 2][operand 2 (A, G)][32-column block 8][split 2][lane 64][16 B] = 64 KiB
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 8 * 2 * kFragBytes];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // 2 buffers of kAtgBufBytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = wave & 3, loads_g = wave >> 2;       // column group; waves 4-7 stream G
-    const int iw = wave & 3, jh = wave >> 2;            // result block: rows 64iw.., columns 128jh..
+    const int op = wave >> 2, w8 = wave & 3;            // operand streamed (0 A, 1 G); rows 8·w8 .. +7 of a super-step
+    const int iw = wave & 3, jh = wave >> 2;            // result block: A tiles 2iw.., G tiles 4jh..
     auto scale_exp = [](float b) {
         int e = 14 - floor_log2f(b);
         e = e > 126 ? 126 : (e < -126 ? -126 : e);
         return (!(b > 0.f) || !(b <= 3.4028235e38f)) ? 0 : e;
     };
     const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
-    const float my_scale = pow2f(loads_g ? g_exp : a_exp);
+    const float my_scale = pow2f(op ? g_exp : a_exp);
     const int back = -(a_exp + g_exp);
     // (an inf / NaN bound = an overflow upstream: poison the result instead of scaling by 1)
     const bool poisoned = !(*a_bound <= 3.4028235e38f) || !(*g_bound <= 3.4028235e38f);
@@ -1163,100 +1170,130 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ib][jb][i] = 0.f;
 
-    const int64_t s0 = (int64_t)blockIdx.x * steps_per_wg;
-    const int64_t total_steps = (n_list + 15) >> 4;
-    const int64_t s1 = s0 + steps_per_wg < total_steps ? s0 + steps_per_wg : total_steps;
-    // the operand this wave streams: 64 columns of it
-    const float *src = (loads_g ? G : A) + 64 * cg + lane;
-    const int64_t ld = loads_g ? ldg : lda;
-    const int32_t *rows = loads_g ? rg : ra;
+    const int64_t total_supers = (n_list + 31) >> 5;
+    const int64_t s0 = (int64_t)blockIdx.x * supers_per_wg;
+    const int64_t s1 = s0 + supers_per_wg < total_supers ? s0 + supers_per_wg : total_supers;
+    const int64_t padded = (n_list + 15) & ~(int64_t)15;                       // length of the index lists
+    const float *src = (op ? G : A) + 4 * lane;
+    const int64_t ld = op ? ldg : lda;
+    const int32_t *rows = op ? rg : ra;
 
-    float ring[kAtgDepth][16];
-    auto fetch = [&](int64_t step, float (&v)[16]) {     // loads only — no arithmetic on the results
-        const int32_t *idx = rows + step * 16;           // (wave-uniform: scalar loads)
+    // NO BRANCH AROUND A LOAD in the loop: a super-step past the end of the slab re-reads the slab's
+    // last one (its rows are then multiplied as zeros) instead of being skipped — with loads under
+    // an `if` hipcc's wait-count pass merges the two paths pessimistically and every pass waits for
+    // nearly all outstanding loads.
+    f32x4 ring[kAtgDepth][8];
+    auto fetch = [&](int64_t ss, f32x4 (&v)[8]) {       // loads only — no arithmetic on the results
+        ss = ss < s1 - 1 ? ss : s1 - 1;
+        int64_t pos = ss * 32 + 8 * w8;                  // (a group of 8 entries lies inside the padded
+        pos = pos < padded - 8 ? pos : padded - 8;       //  list or wholly past it: then any valid group)
+        const int32_t *idx = rows + pos;                 // (wave-uniform: one scalar load)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld];
+        for (int j = 0; j < 8; ++j) v[j] = *(const f32x4 *)(src + (int64_t)idx[j] * ld);
     };
-    auto publish = [&](int64_t step, float (&v)[16], unsigned char *buf) {
-        // scale, zero the rows past the end of the list, swap halves into the two fragments,
-        // split each into (h, m) fp16 parts, store to this wave's four LDS slots
-        uint32_t hh[2][4], mm[2][4];
+#ifndef ATG_ABLATE      /* experiment builds only (tools/build_gemm_variants.sh atg): 4 = no loads in the loop */
+#define ATG_ABLATE 0
+#endif
+    auto publish = [&](int64_t ss, f32x4 (&v)[8], unsigned char *buf) {
+        // scale, zero the rows past the end of the list (and of the slab), split each column's 8
+        // k-values into (h, m) fp16 parts: one 16-byte fragment per tile and split
+        const int64_t end = ss < s1 ? n_list : 0;        // (a super-step of the next slab: all zeros)
+        const int64_t k0 = ss * 32 + 8 * w8;
+        float x[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float lo_k = (step * 16 + j < n_list) ? v[j] * my_scale : 0.f;
-            const float hi_k = (step * 16 + 8 + j < n_list) ? v[8 + j] * my_scale : 0.f;
-            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_k), __float_as_uint(hi_k),
-                                                       false, false);
-            v[j] = __uint_as_float(sw[0]);               // columns 0-31 of the group:  k = 8h + j
-            v[8 + j] = __uint_as_float(sw[1]);           // columns 32-63 of the group: k = 8h + j
+            const bool live = k0 + j < end;              // (uniform)
+            x[j][0] = live ? v[j].x * my_scale : 0.f;
+            x[j][1] = live ? v[j].y * my_scale : 0.f;
+            x[j][2] = live ? v[j].z * my_scale : 0.f;
+            x[j][3] = live ? v[j].w * my_scale : 0.f;
         }
+        // fragment lane: this lane's column slot in the k-half this wave loads; tiles 2q + (lane >> 5)
+        unsigned char *mine = buf + ((size_t)((op * 2 + (w8 >> 1)) * 8 + (lane >> 5)) * 2) * kFragBytes +
+                              ((lane & 31) + 32 * (w8 & 1)) * 16;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int q = 0; q < 4; ++q) {
+            uint32_t hh[4], mm[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x2 p = {v[8 * f + 2 * j], v[8 * f + 2 * j + 1]};
+                f32x2 p = {x[2 * j][q], x[2 * j + 1][q]};
                 const h16x2 ph = __builtin_convertvector(p, h16x2);
                 const f32x2 pb = __builtin_convertvector(ph, f32x2);
-                f32x2 q = {p.x - pb.x, p.y - pb.y};
-                const h16x2 pm = __builtin_convertvector(q, h16x2);
-                hh[f][j] = __builtin_bit_cast(uint32_t, ph);
-                mm[f][j] = __builtin_bit_cast(uint32_t, pm);
+                f32x2 r = {p.x - pb.x, p.y - pb.y};
+                const h16x2 pm = __builtin_convertvector(r, h16x2);
+                hh[j] = __builtin_bit_cast(uint32_t, ph);
+                mm[j] = __builtin_bit_cast(uint32_t, pm);
             }
-        unsigned char *mine = buf + (loads_g * 8 + 2 * cg) * (2 * kFragBytes);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            *(u32x4 *)(mine + ((f * 2 + 0) * 64 + lane) * 16) = u32x4{hh[f][0], hh[f][1], hh[f][2], hh[f][3]};
-            *(u32x4 *)(mine + ((f * 2 + 1) * 64 + lane) * 16) = u32x4{mm[f][0], mm[f][1], mm[f][2], mm[f][3]};
+            unsigned char *tile = mine + (size_t)(2 * q) * 2 * kFragBytes;       // tile 2q + (lane >> 5)
+            *(u32x4 *)(tile) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            *(u32x4 *)(tile + kFragBytes) = u32x4{mm[0], mm[1], mm[2], mm[3]};
         }
     };
 
-#pragma unroll
-    for (int d = 0; d < kAtgDepth; ++d)
-        if (s0 + d < s1) fetch(s0 + d, ring[d]);
-    for (int64_t base = s0; base < s1; base += kAtgDepth) {
+    if (s0 < s1) {                                               // (uniform over the workgroup)
 #pragma unroll
         for (int d = 0; d < kAtgDepth; ++d) {
-            const int64_t s = base + d;
-            if (s < s1) {                                        // (uniform over the workgroup)
-                unsigned char *buf = lds + (int)((s - s0) & 1) * (2 * 8 * 2 * kFragBytes);
-                publish(s, ring[d], buf);
-                if (s + kAtgDepth < s1) fetch(s + kAtgDepth, ring[d]);
+            fetch(s0 + d, ring[d]);
+            // (in THIS order: loads retire in order, and the scheduler, left alone, may issue the
+            //  groups last-first — the loop's first wait would then be for the youngest load)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int64_t base = s0; base < s1; base += kAtgDepth) {
+#pragma unroll
+            for (int d = 0; d < kAtgDepth; ++d) {
+                const int64_t ss = base + d;                     // (ss >= s1 in the last pass: zeros)
+                unsigned char *buf = lds + (int)((ss - s0) & 1) * kAtgBufBytes;
+                // (a scheduling fence: the arithmetic of THIS super-step's publish must not move up
+                //  into the previous one — it would wait there for loads that are one step younger)
+                __builtin_amdgcn_sched_barrier(0);
+                publish(ss, ring[d], buf);
+                if (!(ATG_ABLATE & 4)) fetch(ss + kAtgDepth, ring[d]);
                 __syncthreads();
-                u32x4 Af[2][2];
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const unsigned char *ab = buf + (size_t)((0 * 2 + s2) * 8) * 2 * kFragBytes;
+                    const unsigned char *gbase = buf + (size_t)((1 * 2 + s2) * 8) * 2 * kFragBytes;
+                    u32x4 Af[2][2];
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp)
-                        Af[ib][sp] = *(const u32x4 *)(buf + (((2 * iw + ib) * 2 + sp) * 64 + lane) * 16);
+                    for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) {
-                    const unsigned char *gb = buf + ((8 + 4 * jh + jb) * 2) * kFragBytes;
-                    const u32x4 Bh = *(const u32x4 *)(gb + (0 * 64 + lane) * 16);
-                    const u32x4 Bm = *(const u32x4 *)(gb + (1 * 64 + lane) * 16);
+                        for (int sp = 0; sp < 2; ++sp)
+                            Af[ib][sp] = *(const u32x4 *)(ab + (((2 * iw + ib) * 2 + sp) * 64 + lane) * 16);
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {
-                        f32x16 t = acc[ib][jb];
-                        t = mfma_h(Af[ib][1], Bh, t);
-                        t = mfma_h(Af[ib][0], Bm, t);
-                        t = mfma_h(Af[ib][0], Bh, t);
-                        acc[ib][jb] = t;
+                    for (int jb = 0; jb < 4; ++jb) {
+                        const unsigned char *gb = gbase + ((4 * jh + jb) * 2) * kFragBytes;
+                        const u32x4 Bh = *(const u32x4 *)(gb + (0 * 64 + lane) * 16);
+                        const u32x4 Bm = *(const u32x4 *)(gb + (1 * 64 + lane) * 16);
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) {
+                            f32x16 t = acc[ib][jb];
+                            t = mfma_h(Af[ib][1], Bh, t);
+                            t = mfma_h(Af[ib][0], Bm, t);
+                            t = mfma_h(Af[ib][0], Bh, t);
+                            acc[ib][jb] = t;
+                        }
                     }
                 }
             }
         }
     }
-    // D[i][j]: i = 64*iw + 32*ib + (reg&3) + 8*(reg>>2) + 4*(lane>>5), j = 128*jh + 32*jb + (lane&31)
+    // D[i][j] of tiles (Ta, Tb): i = (reg&3) + 8*(reg>>2) + 4*(lane>>5), j = lane&31;
+    // column of tile T, slot u: 128*(T&1) + 4*u + (T>>1)
     float *out = partial + (size_t)blockIdx.x * (kK * kN);
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
+        for (int jb = 0; jb < 4; ++jb) {
+            const int ta = 2 * iw + ib, tb = 4 * jh + jb;
+            const int col = 128 * (tb & 1) + 4 * c + (tb >> 1);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int i = 64 * iw + 32 * ib + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                out[i * kN + 128 * jh + 32 * jb + c] = acc[ib][jb][reg] * back_a * back_b;
+                const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int row = 128 * (ta & 1) + 4 * i + (ta >> 1);
+                out[row * kN + col] = acc[ib][jb][reg] * back_a * back_b;
             }
+        }
 }
 
 __global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict__ partial, int n_wg,
@@ -1320,22 +1357,23 @@ __global__ __launch_bounds__(256, 2) void gemm_atg128_bf16_kernel(
     const int32_t *rows = op ? rg : ra;
 
     uint32_t ring[kAtgBfDepth][16];
+    // (no branch around a load in the loop — see gemm_atg256_h2_kernel: an iteration past the end
+    //  of the slab, or the odd step past the end of the list, re-reads the last step and is
+    //  multiplied as zeros)
     auto fetch = [&](int64_t it, uint32_t (&v)[16]) {      // loads only
-        const int64_t step = 2 * it + st;
-        if (step < total_steps) {                          // (wave-uniform)
-            const int32_t *idx = rows + step * 16;         // scalar loads
+        it = it < i1 - 1 ? it : i1 - 1;
+        int64_t step = 2 * it + st;
+        step = step < total_steps - 1 ? step : total_steps - 1;
+        const int32_t *idx = rows + step * 16;             // scalar loads
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld2];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0u;
-        }
+        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld2];
     };
     auto publish = [&](int64_t it, uint32_t (&v)[16], unsigned char *buf) {
         const int64_t step = 2 * it + st;
+        const int64_t end = it < i1 ? n_list : 0;          // (an iteration of the next slab: all zeros)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (step * 16 + k >= n_list) v[k] = 0u;        // (uniform: rows past the end of the list)
+            if (step * 16 + k >= end) v[k] = 0u;           // (uniform: rows past the end of the list)
         uint32_t f0[2][4], f1[2][4];                       // [even / odd column][k pair]: rows 0-7, rows 8-15
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1360,17 +1398,19 @@ __global__ __launch_bounds__(256, 2) void gemm_atg128_bf16_kernel(
         }
     };
 
-#pragma unroll
-    for (int d = 0; d < kAtgBfDepth; ++d)
-        if (i0 + d < i1) fetch(i0 + d, ring[d]);
-    for (int64_t base = i0; base < i1; base += kAtgBfDepth) {
+    if (i0 < i1) {                                                           // (uniform over the workgroup)
 #pragma unroll
         for (int d = 0; d < kAtgBfDepth; ++d) {
-            const int64_t it = base + d;
-            if (it < i1) {                                                   // (uniform over the workgroup)
+            fetch(i0 + d, ring[d]);
+            __builtin_amdgcn_sched_barrier(0);                               // (issue order = ring order)
+        }
+        for (int64_t base = i0; base < i1; base += kAtgBfDepth) {
+#pragma unroll
+            for (int d = 0; d < kAtgBfDepth; ++d) {
+                const int64_t it = base + d;                                 // (it >= i1 in the last pass: zeros)
                 unsigned char *buf = lds + (int)((it - i0) & 1) * kAtgBfBuf;
                 publish(it, ring[d], buf);
-                if (it + kAtgBfDepth < i1) fetch(it + kAtgBfDepth, ring[d]);
+                fetch(it + kAtgBfDepth, ring[d]);
                 __syncthreads();
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1626,8 +1666,8 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
 
 static int64_t atg_wgs(int64_t n_list)
 {
-    const int64_t steps = (n_list + 15) / 16;
-    return std::max<int64_t>(1, std::min<int64_t>(kAtgMaxWgs, (steps + kAtgStepsMin - 1) / kAtgStepsMin));
+    const int64_t supers = (n_list + 31) / 32;
+    return std::max<int64_t>(1, std::min<int64_t>(kAtgMaxWgs, (supers + kAtgSuperMin - 1) / kAtgSuperMin));
 }
 
 size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list)
@@ -1654,10 +1694,21 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL pointer");
     if (workspace_bytes < gcn_gemm_atg256_workspace_bytes(n_list))
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_atg256_f32: workspace too small");
+    if ((((uintptr_t)A) | ((uintptr_t)G)) % 16 != 0 || lda % 4 != 0 || ldg % 4 != 0)
+        return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_atg256_f32: A / G rows must be 16-byte aligned");
     const int64_t n_wg = atg_wgs(n_list);
-    const int64_t steps = (n_list + 15) / 16;
-    const int64_t per = (steps + n_wg - 1) / n_wg;
-    hipLaunchKernelGGL(gemm_atg256_h2_kernel, dim3((unsigned)n_wg), dim3(512), 0, s, A, lda, rows_a, G,
+    const int64_t supers = (n_list + 31) / 32;
+    const int64_t per = (supers + n_wg - 1) / n_wg;
+    {
+        static bool lds_set = false;
+        if (!lds_set) {
+            hipError_t ae = hipFuncSetAttribute((const void *)gemm_atg256_h2_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kAtgBufBytes);
+            if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_atg256_f32: LDS size");
+            lds_set = true;
+        }
+    }
+    hipLaunchKernelGGL(gemm_atg256_h2_kernel, dim3((unsigned)n_wg), dim3(512), 2 * kAtgBufBytes, s, A, lda, rows_a, G,
                        ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
     hipLaunchKernelGGL(atg_reduce_kernel, dim3(kK * kN / 256), dim3(256), 0, s, (const float *)workspace,
                        (int)n_wg, out, ldo);

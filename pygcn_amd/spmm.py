@@ -676,7 +676,7 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
             return None
     elif (_gemm_scheme != "h2" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
             or A.dim() != 2 or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
-            or G.stride(1) != 1):
+            or G.stride(1) != 1 or A.stride(0) % 4 or G.stride(0) % 4 or A.data_ptr() % 16 or G.data_ptr() % 16):
         return None
     if n_list is None:
         n_a = rows_a.numel() if rows_a is not None else A.shape[0]
