@@ -340,7 +340,11 @@ __device__ __forceinline__ uint32_t store_out(const KParams &p, int64_t row, int
     }
     if (do_store) {
         T *dst = (T *)p.C + row * p.ldc + f;
+#if SPMM_STORE_NT
+        __builtin_nontemporal_store(Elem<T, VEC>::pack(o), (typename Elem<T, VEC>::Raw *)dst);
+#else
         *(typename Elem<T, VEC>::Raw *)dst = Elem<T, VEC>::pack(o);
+#endif
     }
     uint32_t amax = 0u;
     if (XEPI >= 2 && p.cabsmax != nullptr && do_store) {   // (uniform pointer test)
@@ -375,13 +379,23 @@ __device__ __forceinline__ void publish_absmax(const KParams &p, uint32_t amax)
 // scalars: base = B + col*ldb (SGPR pair), num_records = row bytes.  The hardware range check
 // returns zeros for lanes past the end of the row (feature tail) and for whole slots whose
 // num_records is 0 (slots past the end of an edge tile), so the gather needs no branches.
+#ifndef SPMM_GATHER_AUX    /* experiment builds (tools/build_spmm_variants.sh): cache policy of the gather */
+#define SPMM_GATHER_AUX 0  /* 0 default, 2 = nt (streaming) */
+#endif
+#ifndef SPMM_HUB_TAG       /* 1: bit 31 of a column index marks a HUB column — its row is loaded with the */
+#define SPMM_HUB_TAG 0     /*    default policy, every other row with SPMM_GATHER_AUX                     */
+#endif
+#ifndef SPMM_STORE_NT      /* 1: the result rows are stored non-temporally */
+#define SPMM_STORE_NT 0
+#endif
+template <int AUX = SPMM_GATHER_AUX>
 __device__ __forceinline__ u32x4 row_load16(uint64_t base, uint32_t nbytes, uint32_t voff)
 {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     void *pb = (void *)(((uint64_t)hi << 32) | lo);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pb, 0, nbytes, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, AUX);
 }
 
 template <typename T, int VEC, int D, bool ROWS, bool FLAGS, int XEPI>
@@ -485,8 +499,15 @@ __device__ __forceinline__ void wide_stream(const KParams &p, const int32_t *__r
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const bool ok = k + j < cnt;
+#if SPMM_HUB_TAG
+                const int ct = readlane_i(cv, k + j);
+                const int c = ct & 0x7fffffff;
+                if (ct < 0) x[j] = row_load16<0>(row_base(c), ok ? row_bytes : 0u, ld_off_bytes);
+                else x[j] = row_load16<SPMM_GATHER_AUX>(row_base(c), ok ? row_bytes : 0u, ld_off_bytes);
+#else
                 const int c = readlane_i(cv, k + j);   // k + j <= 63 always (k <= 56)
                 x[j] = row_load16(row_base(c), ok ? row_bytes : 0u, ld_off_bytes);
+#endif
             }
 #pragma unroll
             for (int j = 0; j < D; ++j)
