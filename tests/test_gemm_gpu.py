@@ -433,6 +433,46 @@ def test_bf16_gemm_with_backward_mask_in_the_store(dev):
     assert gemm_bf16(X, W, relu=True, mask_src=H[:M].contiguous()) is None
 
 
+@pytest.mark.parametrize("M", [98_305, 400_003, 196_640])
+def test_bf16_gemm_pipeline_across_tiles(dev, M):
+    """The bf16 GEMM addresses its tiles through buffer descriptors (the range check replaces the
+    tail branch), swaps two fragment register sets between tiles, requests the backward mask ahead
+    of the next tile's prefetch, and leans on counted waits the compiler derives from that order
+    (gcn_gemm.hip).  Heights that give the persistent waves one tile and a second only for some
+    (98 305 = 3 072 waves x 32 rows + 1), several tiles with a ragged last one, and an even split:
+    every store variant must repeat its bits across launches, the masked forms must equal the
+    plain product masked afterwards (scale 1: the same rounding), the row-list form the
+    own-row form, and the plain product an fp64 product of the same bf16 values."""
+    from pygcn_amd.spmm import gemm_bf16
+    g = torch.Generator(device=dev).manual_seed(M)
+    X = torch.randn(M, 128, device=dev, generator=g).bfloat16()
+    W = (torch.randn(128, 128, device=dev, generator=g) * 0.1).bfloat16()
+    H = torch.relu(torch.randn(M, 128, device=dev, generator=g)).bfloat16()
+    bias = torch.randn(128, device=dev, generator=g) * 0.1
+    perm = torch.randperm(M, device=dev, generator=g).to(torch.int32)
+    plain = gemm_bf16(X, W)
+    idx = torch.cat([torch.arange(0, 4096, device=dev), torch.arange(M - 4096, M, device=dev)])
+    ref = X[idx].double() @ W.double()
+    assert (plain[idx].double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    masked = gemm_bf16(X, W, mask_src=H, mask_scale=1.0)
+    assert torch.equal(masked, torch.where(H > 0, plain, torch.zeros_like(plain)))
+    listed = gemm_bf16(X, W, mask_src=H, mask_rows=perm, mask_scale=1.0)
+    assert torch.equal(listed, torch.where(H[perm.long()] > 0, plain, torch.zeros_like(plain)))
+    fwd = gemm_bf16(X, W, bias=bias, relu=True, dropout_p=0.5, seed=99)
+    nodrop = gemm_bf16(X, W, bias=bias, relu=True)
+    kept = fwd != 0
+    assert torch.equal(nodrop == 0, nodrop == 0) and bool((nodrop[kept] > 0).all())
+    # kept elements are the undropped values times 1 / (1 - p) = 2 (exact in bf16 up to the one rounding)
+    assert (fwd[kept].float() - 2.0 * nodrop[kept].float()).abs().max().item() <= 2.0 ** -7 * nodrop.float().abs().max().item() * 2
+    share = kept.float().sum().item() / max(1.0, (nodrop > 0).float().sum().item())
+    assert 0.49 < share < 0.51
+    for _ in range(4):
+        assert torch.equal(gemm_bf16(X, W), plain)
+        assert torch.equal(gemm_bf16(X, W, mask_src=H, mask_scale=1.0), masked)
+        assert torch.equal(gemm_bf16(X, W, mask_src=H, mask_rows=perm, mask_scale=1.0), listed)
+        assert torch.equal(gemm_bf16(X, W, bias=bias, relu=True, dropout_p=0.5, seed=99), fwd)
+
+
 def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev):
     """The fp32 GEMM moves X and W by asynchronous HBM -> LDS DMA with hand-counted waits
     (gcn_gemm.hip, GEMM_H2_XLDS): a wait that is one too weak would show as run-to-run noise.
