@@ -897,6 +897,10 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
 {
     constexpr int KC = K / 16, NB = N / 32;
     constexpr bool FWD_EPI = EPI == 1, MASK = EPI >= 2;
+    // the whole tile's mask (NB x 32 bytes per lane) is requested ahead of the prefetch where the
+    // registers allow it — the 128 x 128 shape of config C5; the wider shapes fetch it per column
+    // block in the store section (a wait on such a load drains the prefetch, but nothing spills)
+    constexpr bool MASK_EARLY = MASK && K <= 128 && N <= 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];    // K * N * 2 bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -954,8 +958,16 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
     int32_t m0 = 0, m1 = 0;
     auto one_tile = [&](const int64_t t, u32x4 (&a_cur)[KC], u32x4 (&a_nxt)[KC], const int32_t m_cur, int32_t &m_nxt) {
         // this lane's 8 stored columns of every (nb, g pair): 16 bytes of the mask each
-        u32x4 mk[NB][2];
-        if (MASK) {
+        u32x4 mk[MASK_EARLY ? NB : 1][2];
+        const unsigned char *mrow_late = nullptr;
+        if (MASK && !MASK_EARLY) {
+            int32_t mc = m_cur;
+            asm volatile("" : "+v"(mc));
+            int64_t mi = t * 32 + r;
+            mi = EPI == 3 ? (int64_t)mc : (mi < M ? mi : M - 1);
+            mrow_late = (const unsigned char *)((const uint16_t *)ep.mask_src + mi * ep.ld_mask) + 16 * h;
+        }
+        if (MASK_EARLY) {
             // (scheduling fences around the mask requests: nothing of this tile — the widening of
             //  m_cur, the swaps of the mask words in the store section — may move to where it would
             //  wait on a load that is younger than the prefetch)
@@ -995,7 +1007,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
                 acc[nb] = mfma(b, a_cur[c], acc[nb]);      // transposed tile: lane = output row
             }
         }
-        if (MASK) __builtin_amdgcn_sched_barrier(0);
+        if (MASK_EARLY) __builtin_amdgcn_sched_barrier(0);
         const int64_t row = t * 32 + r;
         const __amdgpu_buffer_rsrc_t ys = tile_rsrc(Y, ldy, ldy_b, t, N * 2);
         const uint32_t yoff = (uint32_t)r * ldy_b + 16u * h;
@@ -1048,7 +1060,8 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
                     // per lane); the accumulators are still in MFMA layout (4 + 4 columns, the
                     // other half-wave holding the columns in between), so the mask words take the
                     // inverse of the swap the packed results take below.
-                    const u32x4 m = mk[nb][g >> 1];
+                    const u32x4 m = MASK_EARLY ? mk[MASK_EARLY ? nb : 0][g >> 1]
+                                               : *(const u32x4 *)(mrow_late + (32 * nb + 8 * g) * 2);
                     auto ux = __builtin_amdgcn_permlane32_swap(m[0], m[2], false, false);
                     auto uy = __builtin_amdgcn_permlane32_swap(m[1], m[3], false, false);
                     const uint32_t mw[4] = {ux[0], uy[0], ux[1], uy[1]};     // columns of p0, p1, q0, q1

@@ -473,6 +473,27 @@ def test_bf16_gemm_pipeline_across_tiles(dev, M):
         assert torch.equal(gemm_bf16(X, W, bias=bias, relu=True, dropout_p=0.5, seed=99), fwd)
 
 
+@pytest.mark.parametrize("K,N", [(128, 256), (256, 128)])
+def test_bf16_gemm_mask_at_the_wider_shapes(dev, K, N):
+    """The shapes whose accumulators leave no registers for a tile's whole mask fetch it per column
+    block in the store section: same result as the plain product masked afterwards (scale 1), with
+    and without a row list, ragged height, repeatable."""
+    from pygcn_amd.spmm import gemm_bf16
+    M = 70_003
+    g = torch.Generator(device=dev).manual_seed(K + N)
+    X = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    W = (torch.randn(K, N, device=dev, generator=g) * 0.1).bfloat16()
+    H = torch.relu(torch.randn(M, N, device=dev, generator=g)).bfloat16()
+    perm = torch.randperm(M, device=dev, generator=g).to(torch.int32)
+    plain = gemm_bf16(X, W)
+    assert plain is not None
+    masked = gemm_bf16(X, W, mask_src=H, mask_scale=1.0)
+    listed = gemm_bf16(X, W, mask_src=H, mask_rows=perm, mask_scale=1.0)
+    assert torch.equal(masked, torch.where(H > 0, plain, torch.zeros_like(plain)))
+    assert torch.equal(listed, torch.where(H[perm.long()] > 0, plain, torch.zeros_like(plain)))
+    assert torch.equal(gemm_bf16(X, W, mask_src=H, mask_rows=perm, mask_scale=1.0), listed)
+
+
 def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev):
     """The fp32 GEMM moves X and W by asynchronous HBM -> LDS DMA with hand-counted waits
     (gcn_gemm.hip, GEMM_H2_XLDS): a wait that is one too weak would show as run-to-run noise.
