@@ -449,15 +449,19 @@ template <int N> __device__ __forceinline__ void dma_wait()
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-// FWD_EPI = false: plain product / backward mask, persistent with the cross-tile pipeline.
-// FWD_EPI = true: bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
+// EPI 0: plain product; EPI 2: backward mask in the store (its own instantiation, so that no branch
+// surrounds the mask loads: they are requested one column block AHEAD, before the current block's
+// stores, and the wait for them leaves only those stores outstanding — fetched where they were used
+// they cost one drain of all earlier stores per column block); both persistent with the cross-tile pipeline.
+// EPI 1 (FWD_EPI): bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
 // the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
-template <bool FWD_EPI>
+template <int EPI>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
     const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
+    constexpr bool FWD_EPI = EPI == 1, MASKED = EPI == 2;
     const float *__restrict__ mask_src = ep.mask_src;
     const int64_t ld_mask = ep.ld_mask;
     const float mask_scale = ep.mask_scale;
@@ -654,6 +658,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #else
         const float *xrow_n = X + src_n * ldx + 8 * (lane >> 5);
 #endif
+        // (masked form: the row of the mask this lane will read in the store section — looked up
+        //  here, a whole K loop ahead of its use)
+        int64_t mask_row = src_row;
+        if (MASKED && ep.mask_rows != nullptr) mask_row = row_ok ? (int64_t)ep.mask_rows[row] : 0;
         f32x16 acc[8];
 #pragma unroll
         for (int nb = 0; nb < 8; ++nb)
@@ -764,10 +772,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         if (row_ok) {
             float *yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
-            const float *mrow = mask_src
-                ? mask_src + (ep.mask_rows ? (int64_t)ep.mask_rows[row] : src_row) * ld_mask + 4 * (lane >> 5)
-                : nullptr;
+            const float *mrow = MASKED ? mask_src + mask_row * ld_mask + 4 * (lane >> 5) : nullptr;
             const float *bias_p = ep.bias;
+            f32x4 mk[2][4];                 // the mask of column block nb in mk[nb & 1]
+            if (MASKED) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mk[0][g] = *(const f32x4 *)(mrow + 8 * g);
+            }
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) {
                 // dropout: the two Philox calls of this column block (8 keep fields each: groups 0-1 and
@@ -788,14 +799,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                         h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, k0, k1, r8[q]);
                     }
                 }
-                // backward mask: the four 16-byte pieces of this column block are fetched TOGETHER,
-                // ahead of the stores — loads and stores share one counter on gfx9 and may complete
-                // out of order, so a load issued after a store is waited for with vmcnt(0): one
-                // drain per column block instead of one per store
-                f32x4 mk[4];
-                if (!FWD_EPI && mrow != nullptr) {
+                // backward mask: the NEXT column block's four 16-byte pieces are requested here,
+                // ahead of this block's stores (loads and stores retire in order on one counter: the
+                // wait for them at the top of the next block then leaves exactly these 4 stores out)
+                if (MASKED && nb + 1 < 8) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) mk[g] = *(const f32x4 *)(mrow + 32 * nb + 8 * g);
+                    for (int g = 0; g < 4; ++g) mk[(nb + 1) & 1][g] = *(const f32x4 *)(mrow + 32 * (nb + 1) + 8 * g);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -824,8 +833,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                         v.z = (w1 & 0xFFFFu) >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
                         v.w = (w1 >> 16) >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
                     }
-                    if (!FWD_EPI && mrow != nullptr) {
-                        const f32x4 m = mk[g];
+                    if (MASKED) {
+                        const f32x4 m = mk[nb & 1][g];
                         v.x = m.x > 0.f ? v.x * mask_scale : 0.f;
                         v.y = m.y > 0.f ? v.y * mask_scale : 0.f;
                         v.z = m.z > 0.f ? v.z * mask_scale : 0.f;
@@ -1340,6 +1349,11 @@ __global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict
 //     workgroups, the partial products are added in slab order by atg_reduce_kernel_n
 //     (deterministic, no atomics).  Lists are padded to a multiple of 16 entries with valid
 //     indices; rows past n_list are multiplied as zeros.
+// (Measured and NOT adopted here: the branch-free ring of gemm_atg256_h2_kernel — steps past the end
+//  clamped and multiplied as zeros, so that hipcc's counted waits keep two iterations of loads in
+//  flight.  The waits came out as intended (vmcnt 47..32) and the kernel got 10 % SLOWER at full
+//  height, 5.40 against 4.88 ms at C5: with one dword per lane the address unit, not the wait, is
+//  this kernel's limit, and the burst after a drain suits it better.)
 constexpr int kAtgBfDepth = 3;
 constexpr int kAtgBfBuf = 2 * 2 * 4 * kFragBytes;      // [operand 2][step 2][tile 4] fragments = 16 KiB
 
@@ -1370,23 +1384,22 @@ __global__ __launch_bounds__(256, 2) void gemm_atg128_bf16_kernel(
     const int32_t *rows = op ? rg : ra;
 
     uint32_t ring[kAtgBfDepth][16];
-    // (no branch around a load in the loop — see gemm_atg256_h2_kernel: an iteration past the end
-    //  of the slab, or the odd step past the end of the list, re-reads the last step and is
-    //  multiplied as zeros)
     auto fetch = [&](int64_t it, uint32_t (&v)[16]) {      // loads only
-        it = it < i1 - 1 ? it : i1 - 1;
-        int64_t step = 2 * it + st;
-        step = step < total_steps - 1 ? step : total_steps - 1;
-        const int32_t *idx = rows + step * 16;             // scalar loads
+        const int64_t step = 2 * it + st;
+        if (step < total_steps) {                          // (wave-uniform)
+            const int32_t *idx = rows + step * 16;         // scalar loads
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld2];
+            for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)idx[k] * ld2];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = 0u;
+        }
     };
     auto publish = [&](int64_t it, uint32_t (&v)[16], unsigned char *buf) {
         const int64_t step = 2 * it + st;
-        const int64_t end = it < i1 ? n_list : 0;          // (an iteration of the next slab: all zeros)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            if (step * 16 + k >= end) v[k] = 0u;           // (uniform: rows past the end of the list)
+            if (step * 16 + k >= n_list) v[k] = 0u;        // (uniform: rows past the end of the list)
         uint32_t f0[2][4], f1[2][4];                       // [even / odd column][k pair]: rows 0-7, rows 8-15
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1411,19 +1424,17 @@ __global__ __launch_bounds__(256, 2) void gemm_atg128_bf16_kernel(
         }
     };
 
-    if (i0 < i1) {                                                           // (uniform over the workgroup)
+#pragma unroll
+    for (int d = 0; d < kAtgBfDepth; ++d)
+        if (i0 + d < i1) fetch(i0 + d, ring[d]);
+    for (int64_t base = i0; base < i1; base += kAtgBfDepth) {
 #pragma unroll
         for (int d = 0; d < kAtgBfDepth; ++d) {
-            fetch(i0 + d, ring[d]);
-            __builtin_amdgcn_sched_barrier(0);                               // (issue order = ring order)
-        }
-        for (int64_t base = i0; base < i1; base += kAtgBfDepth) {
-#pragma unroll
-            for (int d = 0; d < kAtgBfDepth; ++d) {
-                const int64_t it = base + d;                                 // (it >= i1 in the last pass: zeros)
+            const int64_t it = base + d;
+            if (it < i1) {                                                   // (uniform over the workgroup)
                 unsigned char *buf = lds + (int)((it - i0) & 1) * kAtgBfBuf;
                 publish(it, ring[d], buf);
-                fetch(it + kAtgBfDepth, ring[d]);
+                if (it + kAtgBfDepth < i1) fetch(it + kAtgBfDepth, ring[d]);
                 __syncthreads();
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1557,26 +1568,34 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     if (dyn) {
         static bool raised = false;          // (idempotent; a benign race sets it twice)
         if (!raised) {
-            hipError_t a1 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<true>,
+            hipError_t a1 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<1>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipError_t a2 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<false>,
+            hipError_t a2 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<0>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (a1 != hipSuccess || a2 != hipSuccess)
-                return gcn_internal_fail_hip((int)(a1 != hipSuccess ? a1 : a2), "gcn_gemm_xw256_f32_h2: LDS size");
+            hipError_t a3 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<2>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess)
+                return gcn_internal_fail_hip((int)(a1 != hipSuccess ? a1 : (a2 != hipSuccess ? a2 : a3)),
+                                             "gcn_gemm_xw256_f32_h2: LDS size");
             raised = true;
         }
     }
     if (ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u) {
         const unsigned egrid = GEMM_H2_EPI_PERSIST ? (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID)
                                                    : (unsigned)tiles;
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<true>, dim3(egrid), dim3(kThreads), dyn, s, X, ldx,
+        hipLaunchKernelGGL(gemm_xw256_h2_kernel<1>, dim3(egrid), dim3(kThreads), dyn, s, X, ldx,
                            x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
                            (uint32_t *)y_absmax, ep);
     } else {
         const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<false>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
-                           x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                           (uint32_t *)y_absmax, ep);
+        if (ep.mask_src != nullptr)
+            hipLaunchKernelGGL(gemm_xw256_h2_kernel<2>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
+                               x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                               (uint32_t *)y_absmax, ep);
+        else
+            hipLaunchKernelGGL(gemm_xw256_h2_kernel<0>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
+                               x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
+                               (uint32_t *)y_absmax, ep);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
