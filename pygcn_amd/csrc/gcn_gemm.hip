@@ -1,6 +1,6 @@
 // gcn_gemm.hip — the dense half of GraphConvolution on gfx950 MFMA:
 // `support = torch.mm(input, self.weight)` (reference pygcn/layers.py:33) and the two GEMMs of its
-// backward, at the layer shapes of configs C3–C5.  Four kernels:
+// backward, at the layer shapes of configs C3–C5.  Five kernels:
 //
 //   gemm_xw256_h2_kernel   Y[M,256] = X[M,256]·W[256,256], fp32 in / out (the default).  gfx950 has
 //                          no reduced-precision fp32 MFMA and the exact one runs at 1/16 of the
@@ -14,6 +14,14 @@
 //   gemm_atg256_h2_kernel  grad_W[256,256] = Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] over a row LIST (+ ordered
 //                          slab reduction), the weight gradient without compacting copies.
 //   gemm_bf16_kernel<K,N>  bf16 storage (config C5: 128 -> 128), W resident in LDS, streaming.
+//   gemm_atg128_bf16_kernel the weight gradient at bf16 storage (128 x 128).
+//
+// A rule all of them follow (round 3, DESIGN §3.7 "wait-count audit"): vector loads and stores
+// retire IN ORDER on one counter, so a wait on a young load is a wait on everything older.  No load
+// is consumed where it is issued inside a store section (bias and seed are staged once per
+// workgroup), no data-dependent branch surrounds a memory instruction inside a pipelined loop
+// (buffer descriptors / clamped indices instead), prefetch register sets are swapped by unrolling
+// rather than copied, and `sched_barrier` pins the issue order where the wait counts depend on it.
 //
 // Structure of the fp32 product kernels: a 512-thread workgroup owns 256 rows; each of its 8 waves
 // owns 32 rows x all 256 columns (8 accumulator tiles of 32x32 = 128 VGPRs, held TRANSPOSED so a
@@ -26,10 +34,11 @@
 // opaque asm, or hipcc sinks it back to just after the barrier, where it idles the pipe).  W is
 // split and fragment-ordered once per call by a small prep kernel into the workspace.
 //
-// Measured on MI355X at M = 10^7 (one process, interleaved): h2 5.2 ms (persistent workgroups with
-// a cross-tile pipeline), three bf16 parts 7.5 ms, hipBLASLt fp32 9.95 ms.  The h2 kernel is
+// Measured on MI355X at M = 10^7 (one process, interleaved): h2 4.8 ms plain / 5.1 ms with the layer
+// epilogue (persistent workgroups, X and W by HBM -> LDS DMA, cross-tile pipeline; round 2: 5.2 /
+// 6.9), three bf16 parts 7.5 ms, hipBLASLt fp32 9.95 ms.  The h2 kernel is
 // bound by the CU's vector-memory instruction issue (3e7 wave-level loads / stores of 1 KiB per
-// launch, already 16 B per lane), not by MFMA (37 % busy) or HBM (3.9 TB/s): DESIGN §3.7, with the
+// launch, already 16 B per lane), not by MFMA (48 % busy) or HBM (4.3 TB/s): DESIGN §3.7, with the
 // variants that were measured and rejected in §7 (resident-W column split, stores through LDS,
 // 4-wave workgroups, row pitch, X staged through LDS in full lines, a deeper X ring).
 #include <hip/hip_runtime.h>
