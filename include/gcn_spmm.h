@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 22
+#define GCN_ABI_VERSION 23
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -72,7 +72,9 @@ typedef struct gcn_csr_plan {
     const int32_t *long_chunk0;/* [n_long+1] first chunk of every long row                   */
 } gcn_csr_plan;
 
-/* ABI history: 21 = round 2's surface.  22 (round 3): the dropout keep function draws eight 16-bit
+/* ABI history: 21 = round 2's surface.  23 (round 3, late): at p = 1/2 the dropout keep function
+ * draws 128 one-bit fields per Philox call (other p unchanged) — masks at p = 1/2 differ from ABI
+ * 22's; no signature or struct changed.  22 (round 3): the dropout keep function draws eight 16-bit
  * fields per Philox call instead of four 32-bit words and takes a row base (drop_row_base in both
  * epilogue structs) and the product can report max|result| (gcn_epilogue.c_absmax); new entry
  * points gcn_nll_log_softmax_backward_colsum, gcn_gemm_atg_bf16, gcn_sddmm_csr, gcn_rows_pack_count /
@@ -161,11 +163,14 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
  *   x = max(x, 0)                if relu                     — F.relu,   pygcn/models.py:48 (upstream)
  *   x = keep ? x / (1 - p) : 0   if dropout_p > 0            — F.dropout, pygcn/models.py:50 (upstream)
  * The keep bit of element (row, f) is a pure function of (seed, drop_row_base + row, f), identical
- * for every kernel variant (ABI 22: eight 16-bit fields per Philox4x32-10 call):
+ * for every kernel variant.  T = clamp(round(p * 65536), 1, 65535) (p is honoured to 2^-17; p = 1/2
+ * exactly), w = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi)), and
+ *   T != 32768 (ABI 22: eight 16-bit fields per call):
  *     block = ((f >> 4) << 1) | ((f >> 2) & 1),   field = (((f >> 3) & 1) << 2) | (f & 3)
- *     w     = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi))
- *     keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= T,
- *     T     = clamp(round(p * 65536), 1, 65535)      (p is honoured to 2^-17; p = 1/2 exactly)
+ *     keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= T
+ *   T == 32768, i.e. p = 1/2 — one bit decides (ABI 23: 128 one-bit fields per call):
+ *     block = ((f >> 8) << 1) | ((f >> 2) & 1),   index = (((f & 255) >> 3) << 2) | (f & 3)
+ *     keep  = (w[index >> 5] >> (index & 31)) & 1
  * Because out > 0 <=> (pre-activation > 0 and kept), no mask is stored: the backward pass is
  * gcn_relu_dropout_backward on the output itself.
  */

@@ -324,18 +324,32 @@ def train_trajectory(x, adj, params, labels, idx_train, epochs, lr=0.01, weight_
 # ---------------------------------------------------------------- fused dropout (test checker)
 def dropout_keep(seed, rows, F, p, row_base=0):
     """numpy restatement of the kernels' dropout keep function (include/gcn_spmm.h, struct
-    gcn_epilogue, ABI 22) — the stand-in for the mask `F.dropout` draws in the reference model
-    (pygcn/models.py:50 upstream).  bool [len(rows), F]; element (row, f):
+    gcn_epilogue, ABI 23) — the stand-in for the mask `F.dropout` draws in the reference model
+    (pygcn/models.py:50 upstream).  bool [len(rows), F]; with thresh = clamp(round(p * 65536), 1,
+    65535) and row = rows[i] + row_base, element (row, f):
+      thresh != 32768 — eight 16-bit fields per Philox call:
         block = ((f >> 4) << 1) | ((f >> 2) & 1),   field = (((f >> 3) & 1) << 2) | (f & 3)
         w     = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi))
-        keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= clamp(round(p * 65536), 1, 65535)
-    with row = rows[i] + row_base."""
+        keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= thresh
+      thresh == 32768 (p = 1/2, the reference's default: one bit decides) — 128 one-bit fields per call:
+        block = ((f >> 8) << 1) | ((f >> 2) & 1),   index = (((f & 255) >> 3) << 2) | (f & 3)
+        keep  = (w[index >> 5] >> (index & 31)) & 1
+    Both are the same layout rule — a call covers the columns {2E·c + 8·q + 4·b + (0..3)} of one
+    parity b of bit 2 of f, E = 8 or 128 fields — so that one lane of the MFMA GEMMs' transposed
+    accumulator tile finds all its columns of a span in one call."""
     M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
     mask32 = np.uint64(0xFFFFFFFF)
     rows = np.asarray(rows, np.int64) + np.int64(row_base)
     f = np.arange(F, dtype=np.int64)
-    blk = ((f >> 4) << 1) | ((f >> 2) & 1)
-    fld = (((f >> 3) & 1) << 2) | (f & 3)
+    t = int(np.float64(np.float32(p)) * 65536.0 + 0.5)
+    thresh = min(65535, max(1, t))
+    one_bit = thresh == 32768
+    if one_bit:
+        blk = ((f >> 8) << 1) | ((f >> 2) & 1)
+        fld = (((f & 255) >> 3) << 2) | (f & 3)                               # 0..127
+    else:
+        blk = ((f >> 4) << 1) | ((f >> 2) & 1)
+        fld = (((f >> 3) & 1) << 2) | (f & 3)                                 # 0..7
     blocks = np.unique(blk)
     r = np.repeat(rows.astype(np.uint64), len(blocks))
     q = np.tile(blocks.astype(np.uint64), len(rows))
@@ -348,8 +362,9 @@ def dropout_keep(seed, rows, F, p, row_base=0):
         k0, k1 = (k0 + np.uint64(W0)) & mask32, (k1 + np.uint64(W1)) & mask32
     words = np.stack(c, axis=1).reshape(len(rows), len(blocks), 4)          # [row, block, word]
     bpos = np.searchsorted(blocks, blk)
+    if one_bit:
+        w = words[:, bpos, fld >> 5]                                          # [row, F]
+        return ((w >> (fld & 31).astype(np.uint64)) & np.uint64(1)) != 0
     w = words[:, bpos, fld >> 1]                                              # [row, F]
     bits = (w >> (np.uint64(16) * (fld & 1).astype(np.uint64))) & np.uint64(0xFFFF)
-    t = int(np.float64(np.float32(p)) * 65536.0 + 0.5)
-    thresh = min(65535, max(1, t))
     return bits >= np.uint64(thresh)

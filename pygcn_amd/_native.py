@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (GCN_SPMM_LIB: an experiment build of the same ABI — tools/*_variant_sweep.py; never set in product use)
 LIB_PATH = os.environ.get("GCN_SPMM_LIB") or os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 22
+GCN_ABI_VERSION = 23
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64

@@ -470,7 +470,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
-    constexpr bool FWD_EPI = EPI == 1, MASKED = EPI == 2;
+    // EPI: 0 plain, 2 backward mask; forward epilogues (bias always, zeros when there is none):
+    // 1 bias only, 4 + ReLU, 5 + ReLU + dropout at p = 1/2 (one-bit keep fields), 6 + ReLU + dropout
+    // at any other p (16-bit fields).  Compile-time options: a uniform branch per column group in
+    // the store section costs this issue-bound kernel more than the arithmetic it skips.
+    constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASKED = EPI == 2;
+    constexpr bool RELU = EPI >= 4, DROP1 = EPI == 5, DROP16 = EPI == 6;
     const float *__restrict__ mask_src = ep.mask_src;
     const int64_t ld_mask = ep.ld_mask;
     const float mask_scale = ep.mask_scale;
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     __shared__ __attribute__((aligned(16))) float bias_lds[FWD_EPI ? kN : 4];
     uint32_t seed_k0 = ep.seed_lo, seed_k1 = ep.seed_hi;
     if (FWD_EPI) {
-        if (ep.bias != nullptr && tid < kN) bias_lds[tid] = ep.bias[tid];
+        if (tid < kN) bias_lds[tid] = ep.bias != nullptr ? ep.bias[tid] : 0.f;
         if (ep.seed_dev != nullptr) {
             const uint64_t sd = *ep.seed_dev;
             seed_k0 = (uint32_t)sd;
@@ -782,7 +787,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             float *yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
             const float *mrow = MASKED ? mask_src + mask_row * ld_mask + 4 * (lane >> 5) : nullptr;
-            const float *bias_p = ep.bias;
+            // dropout at p = 1/2: 128 one-bit keep fields per Philox call (gcn_spmm.hip,
+            // apply_dropout) — ONE call covers all of this lane's 128 columns of the row
+            // (block = this lane's half h; column 32nb + 8g + 4h + j is bit 16(nb & 1) + 4g + j of
+            // word nb >> 1); other p: eight 16-bit fields per call, 16 calls per lane and tile
+            uint32_t r1[4] = {0u, 0u, 0u, 0u};
+            if (DROP1) {
+                const int64_t drow = row + ep.drop_row_base;
+                uint32_t cw = (uint32_t)(lane >> 5);
+                asm volatile("" : "+v"(cw));
+                h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, seed_k0, seed_k1, r1);
+            }
             f32x4 mk[2][4];                 // the mask of column block nb in mk[nb & 1]
             if (MASKED) {
 #pragma unroll
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 // 32 x 32 -> 64 multiplies interleave; the scheduling barrier below then sits between
                 // column blocks, not between the chains
                 uint32_t r8[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-                if (FWD_EPI && ep.drop_thresh != 0u) {                        // (uniform branch)
+                if (DROP16) {
                     const uint32_t k0 = seed_k0, k1 = seed_k1;
                     const int64_t drow = row + ep.drop_row_base;
 #pragma unroll
@@ -825,16 +840,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     // forward epilogue of the layer when the GEMM is its LAST stage
                     // ((Â·X)·W + b, pygcn/layers.py:33-36 reassociated): bias, ReLU, inverted dropout
                     const int f = 32 * nb + 8 * g + 4 * (lane >> 5);          // first of 4 columns
-                    if (FWD_EPI && bias_p != nullptr) {
+                    if (FWD_EPI) {
                         // this lane's 4 bias values from LDS (a broadcast read: lgkmcnt, not vmcnt)
                         const f32x4 b4 = *(const f32x4 *)(bias_lds + f);
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                     }
-                    if (FWD_EPI && ep.relu) {
+                    if (RELU) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                         v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
-                    if (FWD_EPI && ep.drop_thresh != 0u) {                    // (uniform branch)
+                    if (DROP1) {
+                        const uint32_t nib = r1[nb >> 1] >> (16 * (nb & 1) + 4 * g);
+                        v.x = (nib & 1u) ? v.x * ep.drop_scale : 0.f;
+                        v.y = (nib & 2u) ? v.y * ep.drop_scale : 0.f;
+                        v.z = (nib & 4u) ? v.z * ep.drop_scale : 0.f;
+                        v.w = (nib & 8u) ? v.w * ep.drop_scale : 0.f;
+                    } else if (DROP16) {
                         const uint32_t *rq = r8[g >> 1];
                         const uint32_t w0 = (g & 1) ? rq[2] : rq[0], w1 = (g & 1) ? rq[3] : rq[1];
                         v.x = (w0 & 0xFFFFu) >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
@@ -854,7 +875,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #endif
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
                     if (y_absmax != nullptr) {                                 // (wave-uniform)
-                        if (FWD_EPI && ep.relu)      // stored values are >= 0 (or NaN): the bits as they are
+                        if (RELU)                    // stored values are >= 0 (or NaN): the bits as they are
                             vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
                                        max(__float_as_uint(v.z), __float_as_uint(v.w)));
                         else
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 }
                 // (keeps hipcc from running all 16 Philox chains of the tile side by side — 64 live
                 //  registers on top of the accumulators)
-                if (FWD_EPI) __builtin_amdgcn_sched_barrier(0);
+                if (DROP16) __builtin_amdgcn_sched_barrier(0);
             }
         }
         row = row_n;
@@ -909,12 +930,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 // fragments (loads retire in order: a wait on the mask must not drain the prefetch), its row-list
 // entry one tile ahead.
 template <int K, int N, int EPI>
-__global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) : 2)) void gemm_bf16_kernel(
+__global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? ((EPI == 2 || EPI == 3) ? 2 : 3) : 2)) void gemm_bf16_kernel(
     const uint16_t *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ wimg,
     uint16_t *__restrict__ Y, int64_t ldy, int64_t M, int64_t n_tiles, const H2Epi ep)
 {
     constexpr int KC = K / 16, NB = N / 32;
-    constexpr bool FWD_EPI = EPI == 1, MASK = EPI >= 2;
+    // EPI: 0 plain, 2 / 3 backward mask (own row / row list); forward epilogues as in
+    // gemm_xw256_h2_kernel: 1 bias, 4 + ReLU, 5 + dropout at p = 1/2, 6 + dropout at another p
+    constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASK = EPI == 2 || EPI == 3;
+    constexpr bool RELU = EPI >= 4, DROP1 = EPI == 5, DROP16 = EPI == 6;
     // the whole tile's mask (NB x 32 bytes per lane) is requested ahead of the prefetch where the
     // registers allow it — the 128 x 128 shape of config C5; the wider shapes fetch it per column
     // block in the store section (a wait on such a load drains the prefetch, but nothing spills)
@@ -932,7 +956,7 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
     __shared__ __attribute__((aligned(16))) float bias_lds[FWD_EPI ? N : 4];
     uint32_t seed_k0 = ep.seed_lo, seed_k1 = ep.seed_hi;
     if (FWD_EPI) {
-        if (ep.bias != nullptr && tid < N) bias_lds[tid] = ep.bias[tid];
+        if (tid < N) bias_lds[tid] = ep.bias != nullptr ? ep.bias[tid] : 0.f;
         if (ep.seed_dev != nullptr) {
             const uint64_t sd = *ep.seed_dev;
             seed_k0 = (uint32_t)sd;
@@ -1027,6 +1051,13 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
         }
         if (MASK_EARLY) __builtin_amdgcn_sched_barrier(0);
         const int64_t row = t * 32 + r;
+        uint32_t r1[4] = {0u, 0u, 0u, 0u};                                   // p = 1/2: one-bit fields
+        if (DROP1) {
+            const int64_t drow = row + ep.drop_row_base;
+            uint32_t cw = (uint32_t)h;
+            asm volatile("" : "+v"(cw));
+            h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, seed_k0, seed_k1, r1);
+        }
         const __amdgpu_buffer_rsrc_t ys = tile_rsrc(Y, ldy, ldy_b, t, N * 2);
         const uint32_t yoff = (uint32_t)r * ldy_b + 16u * h;
 #pragma unroll
@@ -1037,20 +1068,27 @@ __global__ __launch_bounds__(256, ((K <= 128 && N <= 128) ? (EPI >= 2 ? 2 : 3) :
                     // the layer's forward epilogue on the fp32 accumulators (the layer evaluated
                     // as (Â·X)·W + b, its last stage being this GEMM): bias, ReLU, Philox
                     // dropout — the keep function of gcn_spmm.hip, one Philox call per 8 columns
+                    // (at p = 1/2: one call per lane and tile, r1 above)
                     uint32_t r4[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int gg = g; gg < g + 2; ++gg) {
                         float v[4] = {acc[nb][4 * gg], acc[nb][4 * gg + 1], acc[nb][4 * gg + 2],
                                       acc[nb][4 * gg + 3]};
-                        if (ep.bias != nullptr) {
+                        {
                             const f32x4 b4 = *(const f32x4 *)(bias_lds + 32 * nb + 8 * gg + 4 * h);
                             v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                         }
-                        if (ep.relu) {
+                        if (RELU) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         }
-                        if (ep.drop_thresh != 0u) {                            // (uniform branch)
+                        if (DROP1) {
+                            const uint32_t nib = r1[nb >> 1] >> (16 * (nb & 1) + 4 * gg);
+                            v[0] = (nib & 1u) ? v[0] * ep.drop_scale : 0.f;
+                            v[1] = (nib & 2u) ? v[1] * ep.drop_scale : 0.f;
+                            v[2] = (nib & 4u) ? v[2] * ep.drop_scale : 0.f;
+                            v[3] = (nib & 8u) ? v[3] * ep.drop_scale : 0.f;
+                        } else if (DROP16) {
                             if (gg == g) {       // one call for the pair of groups g, g + 1
                                 const uint32_t k0 = seed_k0, k1 = seed_k1;
                                 uint32_t cw = ((uint32_t)(2 * nb + (g >> 1)) << 1) | (uint32_t)h;
@@ -1577,35 +1615,34 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     if (dyn) {
         static bool raised = false;          // (idempotent; a benign race sets it twice)
         if (!raised) {
-            hipError_t a1 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<1>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipError_t a2 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<0>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            hipError_t a3 = hipFuncSetAttribute((const void *)gemm_xw256_h2_kernel<2>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess)
-                return gcn_internal_fail_hip((int)(a1 != hipSuccess ? a1 : (a2 != hipSuccess ? a2 : a3)),
-                                             "gcn_gemm_xw256_f32_h2: LDS size");
+            const void *all[] = {(const void *)gemm_xw256_h2_kernel<0>, (const void *)gemm_xw256_h2_kernel<1>,
+                                 (const void *)gemm_xw256_h2_kernel<2>, (const void *)gemm_xw256_h2_kernel<4>,
+                                 (const void *)gemm_xw256_h2_kernel<5>, (const void *)gemm_xw256_h2_kernel<6>};
+            for (const void *k : all) {
+                hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_h2: LDS size");
+            }
             raised = true;
         }
     }
-    if (ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u) {
-        const unsigned egrid = GEMM_H2_EPI_PERSIST ? (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID)
-                                                   : (unsigned)tiles;
-        hipLaunchKernelGGL(gemm_xw256_h2_kernel<1>, dim3(egrid), dim3(kThreads), dyn, s, X, ldx,
-                           x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                           (uint32_t *)y_absmax, ep);
-    } else {
-        const unsigned grid = (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
-        if (ep.mask_src != nullptr)
-            hipLaunchKernelGGL(gemm_xw256_h2_kernel<2>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
-                               x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                               (uint32_t *)y_absmax, ep);
-        else
-            hipLaunchKernelGGL(gemm_xw256_h2_kernel<0>, dim3(grid), dim3(kThreads), dyn, s, X, ldx,
-                               x_rows, (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M,
-                               (uint32_t *)y_absmax, ep);
+    // instantiation by store section (compile-time options, see the kernel): 0 plain, 2 backward mask,
+    // 1 bias, 4 bias + ReLU, 5 + dropout at p = 1/2 (one-bit keep fields), 6 + dropout at another p
+    const bool fwd = ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u;
+    const int variant = !fwd ? (ep.mask_src != nullptr ? 2 : 0)
+                             : (!ep.relu ? 1 : (ep.drop_thresh == 0u ? 4 : (ep.drop_thresh == 32768u ? 5 : 6)));
+    const unsigned grid = (fwd && !GEMM_H2_EPI_PERSIST) ? (unsigned)tiles : (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
+#define GCN_LAUNCH_H2(V)                                                                             \
+    hipLaunchKernelGGL(gemm_xw256_h2_kernel<V>, dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows,  \
+                       (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep)
+    switch (variant) {
+    case 0: GCN_LAUNCH_H2(0); break;
+    case 1: GCN_LAUNCH_H2(1); break;
+    case 2: GCN_LAUNCH_H2(2); break;
+    case 4: GCN_LAUNCH_H2(4); break;
+    case 5: GCN_LAUNCH_H2(5); break;
+    default: GCN_LAUNCH_H2(6); break;
     }
+#undef GCN_LAUNCH_H2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
     return 0;
@@ -1690,7 +1727,10 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
     } while (0)
 #define GCN_LAUNCH_BF16(KK, NN)                                                                     \
     do {                                                                                            \
-        if (fwd) GCN_LAUNCH_BF16_E(KK, NN, 1);                                                      \
+        if (fwd && !ep.relu) GCN_LAUNCH_BF16_E(KK, NN, 1);                                          \
+        else if (fwd && ep.drop_thresh == 0u) GCN_LAUNCH_BF16_E(KK, NN, 4);                         \
+        else if (fwd && ep.drop_thresh == 32768u) GCN_LAUNCH_BF16_E(KK, NN, 5);                     \
+        else if (fwd) GCN_LAUNCH_BF16_E(KK, NN, 6);                                                 \
         else if (ep.mask_src == nullptr) GCN_LAUNCH_BF16_E(KK, NN, 0);                              \
         else if (ep.mask_rows == nullptr) GCN_LAUNCH_BF16_E(KK, NN, 2);                             \
         else GCN_LAUNCH_BF16_E(KK, NN, 3);                                                          \

@@ -194,7 +194,8 @@ __device__ __forceinline__ float readlane_f(float v, int l)
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so the dropout mask of element (row, f)
 // depends only on (seed, row, f) — never on which kernel variant, vector width, wave or launch
 // produced the row.  One call yields 128 bits = EIGHT 16-bit keep fields (ABI 22; before: four
-// 32-bit words — half the integer multiplies per element now).  Element (row, f):
+// 32-bit words — half the integer multiplies per element now) — or, at p = 1/2 where one bit
+// decides, 128 ONE-bit fields (ABI 23, see apply_dropout).  Element (row, f), 16-bit form:
 //     block = ((f >> 4) << 1) | ((f >> 2) & 1)          counter word 2
 //     field = (((f >> 3) & 1) << 2) | (f & 3)           0..7: word field >> 1, half field & 1
 //     w     = philox(counter = (row_lo, row_hi, block, 0), key = seed)   (row incl. drop_row_base)
@@ -230,6 +231,27 @@ __device__ __forceinline__ void apply_dropout(const KParams &p, int64_t row, int
         k1 = (uint32_t)(sd >> 32);
     }
     row += p.drop_row_base;
+    if (p.drop_thresh == 32768u) {
+        // p = 1/2 (the reference's default): ONE bit decides, a call yields 128 one-bit fields —
+        //     block = ((f >> 8) << 1) | ((f >> 2) & 1),   index = (((f & 255) >> 3) << 2) | (f & 3)
+        //     keep  = (w[index >> 5] >> (index & 31)) & 1
+        // the same layout rule at a 256-column span: a lane of the GEMMs' transposed accumulator
+        // tile finds ALL its columns of a 256-wide row in one call (16 calls per tile before).
+#pragma unroll
+        for (int q = 0; q < (VEC + 3) / 4; ++q) {
+            const int fq = f + 4 * q;
+            const uint32_t blk = ((uint32_t)(fq >> 8) << 1) | ((uint32_t)(fq >> 2) & 1u);
+            const int idx = (((fq & 255) >> 3) << 2) | (fq & 3);          // (VEC >= 4: fq & 3 == 0)
+            philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), blk, 0u, k0, k1, r);
+            const int ws = idx >> 5;
+            const uint32_t w = (ws & 2) ? ((ws & 1) ? r[3] : r[2]) : ((ws & 1) ? r[1] : r[0]);
+            const uint32_t nib = w >> (idx & 31);
+#pragma unroll
+            for (int j = 0; j < (VEC == 1 ? 1 : 4); ++j)
+                o[4 * q + j] = ((nib >> j) & 1u) ? o[4 * q + j] * p.drop_scale : 0.f;
+        }
+        return;
+    }
     if (VEC == 1) {
         const uint32_t blk = ((uint32_t)(f >> 4) << 1) | ((uint32_t)(f >> 2) & 1u);
         const int fld = (((f >> 3) & 1) << 2) | (f & 3);

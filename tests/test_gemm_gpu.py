@@ -268,7 +268,7 @@ def test_gemm_with_fused_relu_dropout_mask(dev):
     assert torch.equal(got_r, want[rows.long()])
 
 
-@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("p", [0.0, 0.3, 0.5])
 def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p):
     """bias + ReLU + inverted dropout in the GEMM's store (a layer evaluated as (Â·X)·W + b): the
     same values — and the SAME Philox keep bits for a given (seed, row, column) — as the SpMM
@@ -306,7 +306,7 @@ def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p):
 
 
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128)])
-@pytest.mark.parametrize("p", [0.0, 0.4])
+@pytest.mark.parametrize("p", [0.0, 0.4, 0.5])
 def test_bf16_gemm_forward_epilogue(dev, K, N, p):
     """bias + ReLU + inverted dropout on the fp32 accumulators of the bf16 GEMM, rounded to bf16
     once; the keep bits are those of the SpMM epilogue for the same (seed, row, column) — read off

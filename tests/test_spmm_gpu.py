@@ -327,27 +327,29 @@ def test_batched_samples_match_per_sample_loop(oracle, dev):
     assert_normwise(loop.detach().cpu(), y.detach().cpu().numpy(), TOL, "loop vs batched")
 
 
+@pytest.mark.parametrize("p", [0.5, 0.3])
 @pytest.mark.parametrize("F,dtype", [(256, torch.float32), (16, torch.float32), (7, torch.float32),
-                                     (300, torch.float32), (128, torch.bfloat16)])
-def test_fused_relu_dropout_epilogue_matches_philox_restatement(oracle, dev, F, dtype):
+                                     (300, torch.float32), (1024, torch.float32), (128, torch.bfloat16)])
+def test_fused_relu_dropout_epilogue_matches_philox_restatement(oracle, dev, F, dtype, p):
     """Row f1: bias + ReLU + inverted dropout inside the store.  The mask is a pure function of
     (seed, row, f): restated in numpy (oracle.dropout_keep) and compared exactly, for every kernel
-    variant (wide, narrow vector, narrow scalar, bf16, long rows)."""
+    variant (wide, narrow vector, narrow scalar, bf16, long rows) and both forms of the keep
+    function (p = 1/2: 128 one-bit fields per Philox call; any other p: eight 16-bit fields)."""
     from pygcn_amd import spmm_csr
     n = 1500
     a = _skewed_csr(oracle, n, n, 6, seed=5, hubs=((2, 900), (700, 300)), empties=60)
     g = _graph(a, dev)
     B = torch.from_numpy(gin.dense((n, F), 11)).to(dtype)
     b = gin.dense((F,), 12)
-    p, seed = 0.5, 0x1234567890ABCDEF
+    seed = 0x1234567890ABCDEF
     plain = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True).float().cpu().numpy()
     out = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True, dropout_p=p,
                    seed=seed).float().cpu().numpy()
     keep = oracle.dropout_keep(seed, np.arange(n), F, p)
-    assert 0.47 < keep.mean() < 0.53
+    assert abs(keep.mean() - (1 - p)) < 0.03
     np.testing.assert_array_equal(out[~keep], 0.0)
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-6
-    np.testing.assert_allclose(out[keep], plain[keep] * 2.0, rtol=tol, atol=1e-30)
+    np.testing.assert_allclose(out[keep], plain[keep] * np.float32(1.0 / (1.0 - p)), rtol=tol, atol=1e-30)
     out2 = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True, dropout_p=p,
                     seed=seed + 1).float().cpu().numpy()
     assert (out2 == 0).mean() != (out == 0).mean() or not np.array_equal(out2 == 0, out == 0)
@@ -1152,7 +1154,8 @@ def test_colsum_pass_refuses_row_bitmap_for_rows_wider_than_a_wavefront(dev):
     assert torch.equal(res, want) and torch.allclose(colsum, want.sum(0), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("F,dtype,p", [(256, torch.float32, 0.5), (64, torch.float32, 0.1), (128, torch.bfloat16, 0.3)])
+@pytest.mark.parametrize("F,dtype,p", [(256, torch.float32, 0.5), (256, torch.float32, 0.25), (64, torch.float32, 0.1),
+                                       (128, torch.bfloat16, 0.3), (128, torch.bfloat16, 0.5)])
 def test_dropout_row_base_gives_a_shard_the_masks_of_the_whole(oracle, dev, F, dtype, p):
     """ABI 22: `drop_row_base` is added to the row index in the dropout counter — a row-block shard
     that passes its first global row draws exactly the masks the single-GPU run draws for those
