@@ -1,6 +1,7 @@
 """Ablation sweep of gcn_gemm_atg256_f32 (weight gradient Aᵀ·G, fp32 256 x 256, M = 10^7): every
 variant is a libgcn_*.so built with a different -DATG_ABLATE (tools/build_gemm_variants.sh atg) —
-what the kernel costs without its MFMAs, without the fp16 split, without its loads.
+what the kernel costs without the loads of its step loop (the arithmetic alone).  (Variants that
+drop the MFMAs or the fp16 split tell nothing: hipcc then removes the whole loop as dead code.)
 Usage: python tools/atg_variant_sweep.py build/variants/*.so"""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
