@@ -879,47 +879,66 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void spmm_narrow_kernel(KPar
 // ------------------------------------------------------------------------------------------
 // long rows: add the chunk partials in chunk order, apply the epilogue, write the row
 // ------------------------------------------------------------------------------------------
+// Sum of column f over the chunk partials c0 .. c1-1 of one long row: SIXTEEN independent running
+// sums — sixteen loads in flight per thread — combined in a fixed order: the result depends only
+// on (c0, c1), never on scheduling.  (One running sum made every load wait for the previous add:
+// a hub row of config C5 has > 1 000 chunks, and the serial chain of L2 round trips of that ONE
+// row set the kernel's time, 1.0-1.7 ms per launch.)
+__device__ __forceinline__ float long_row_sum(const float *__restrict__ partial, int F, int f, int c0, int c1)
+{
+    float s[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] = 0.f;
+    int c = c0;
+    for (; c + 16 <= c1; c += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k] += partial[(int64_t)(c + k) * F + f];
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k)
+        if (c + k < c1) s[k] += partial[(int64_t)(c + k) * F + f];
+    return (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+           (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+}
+
+// ONE WAVE per long row, four rows per workgroup: config C5 has 7.4e5 long rows of 4.5 chunks on
+// average (long_thresh 256), and a 256-thread workgroup per row — half of its threads idle at
+// F = 128 — made the launch dispatch-bound (1.1 ms for 1.7 GB of partials).  A lane owns the
+// columns lane, lane + 64, ...: one chunk row is a coalesced 256-byte read per pass.
 template <typename T>
 __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
 {
-    const int j = blockIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= p.n_long) return;
     const int64_t row = p.long_row[j];
     if (p.csel != nullptr && !row_bit(p.csel, (int)row)) return;   // (its chunks were skipped too)
     const int c0 = p.long_chunk0[j], c1 = p.long_chunk0[j + 1];
     uint32_t amax = 0u;
     if (p.log_softmax) {
-        // F <= 512 (host check): thread t owns columns t and t + 256; block-wide max and sum
-        __shared__ float red[2][4];
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        float z[2], m = -INFINITY;
+        // F <= 512 (host check): the lane owns columns lane + 64k, k < 8; wave-wide max and sum
+        // (8-byte loads of column pairs were measured: no faster — the launch is bound by its
+        //  dependent index loads per row, not by the width of the partial reads)
+        auto col = [&](int k) { return lane + kWave * k; };
+        float z[8], m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int f = threadIdx.x + 256 * k;
+        for (int k = 0; k < 8; ++k) {
+            const int f = col(k);
             z[k] = -INFINITY;
-            if (f < p.F) {
-                float s = 0.f;
-                for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
-                z[k] = s + (p.bias ? p.bias[f] : 0.f);
-            }
+            if (f < p.F) z[k] = long_row_sum(p.partial, p.F, f, c0, c1) + (p.bias ? p.bias[f] : 0.f);
             m = fmaxf(m, z[k]);
         }
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-        if (lane == 0) red[0][w] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
         float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) se += (threadIdx.x + 256 * k < p.F) ? expf(z[k] - m) : 0.f;
+        for (int k = 0; k < 8; ++k) se += (col(k) < p.F) ? expf(z[k] - m) : 0.f;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) se += __shfl_xor(se, off, kWave);
-        if (lane == 0) red[1][w] = se;
-        __syncthreads();
-        const float lse = m + logf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        const float lse = m + logf(se);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int f = threadIdx.x + 256 * k;
+        for (int k = 0; k < 8; ++k) {
+            const int f = col(k);
             if (f < p.F) {
                 const float o[1] = {z[k] - lse};
                 ((T *)p.C)[row * p.ldc + f] = Elem<T, 1>::pack(o);
@@ -932,9 +951,8 @@ __global__ __launch_bounds__(256) void spmm_long_reduce_kernel(KParams p)
         publish_absmax<2>(p, amax);
         return;
     }
-    for (int f = threadIdx.x; f < p.F; f += blockDim.x) {
-        float s = 0.f;
-        for (int c = c0; c < c1; ++c) s += p.partial[(int64_t)c * p.F + f];
+    for (int f = lane; f < p.F; f += kWave) {
+        const float s = long_row_sum(p.partial, p.F, f, c0, c1);
         float a[1] = {s};
         float b[1] = {p.bias ? p.bias[f] : 0.f};
         amax = max(amax, store_out<T, 1, 1, 2, false>(p, row, f, true, a, b));   // long rows: always stored
@@ -1261,7 +1279,7 @@ int spmm_typed(const gcn_csr_plan *plan, KParams &kp, hipStream_t s)
         if (e != hipSuccess) return fail_hip(e, "spmm launch");
     }
     if (kp.n_long > 0) {
-        hipLaunchKernelGGL((spmm_long_reduce_kernel<T>), dim3((unsigned)kp.n_long), dim3(256), 0,
+        hipLaunchKernelGGL((spmm_long_reduce_kernel<T>), dim3((unsigned)((kp.n_long + 3) / 4)), dim3(256), 0,
                            s, kp);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail_hip(e, "long-row reduce launch");

@@ -93,6 +93,7 @@ class CSRGraph:
         self.long_thresh = int(long_thresh)
         self._plan = None
         self._keep = None
+        self._plans_extra = {}        # chunk length -> (plan, arrays): plan(dtype) for bf16 storage
         self._t = None
         self._t_val_version = None
         self._inf_norm = None
@@ -209,31 +210,47 @@ class CSRGraph:
                    torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape, **kw)
 
     # ------------------------------------------------------------------ schedule
-    def plan(self):
+    def plan(self, dtype=None):
         """`struct gcn_csr_plan` for this matrix (built once, cached) by the DEVICE planner
         (`gcn_plan_count_device` / `gcn_plan_fill_device`): the row pointer never leaves HBM; the
-        only host transfer is the 24-byte read of (n_items, n_chunks, n_long)."""
+        only host transfer is the 24-byte read of (n_items, n_chunks, n_long).
+        `dtype`: storage type of the dense operand the plan will be used with.  A graph built
+        without an explicit `long_thresh` chunks its long rows at the C-ABI default for fp32
+        storage and at tuning.LONG_THRESH_BF16 for bf16 storage (a second cached schedule)."""
+        if self.long_thresh <= 0 and dtype == torch.bfloat16:
+            from . import tuning
+            return self._plan_for(tuning.LONG_THRESH_BF16)
         if self._plan is not None:
             return self._plan
         if self._keep is None:
-            self._keep = self._plan_arrays_device()
-        keep = self._keep
+            self._keep = self._plan_arrays_device(self.long_thresh)
+        self._plan = self._plan_struct(self._keep, self.long_thresh if self.long_thresh > 0
+                                       else _native.GCN_DEFAULT_LONG_THRESH)
+        return self._plan
+
+    def _plan_for(self, thresh):
+        """The schedule at another chunk length (cached beside the default one)."""
+        hit = self._plans_extra.get(thresh)
+        if hit is None:
+            keep = self._plan_arrays_device(thresh)
+            hit = self._plans_extra[thresh] = (self._plan_struct(keep, thresh), keep)
+        return hit[0]
+
+    def _plan_struct(self, keep, thresh):
         ni, nc, nl = keep["n_items"], keep["n_chunks"], keep["n_long"]
         p = _native.GcnCsrPlan()
         p.n_rows, p.n_cols, p.nnz = self.shape[0], self.shape[1], self.nnz
         p.rowptr, p.rowptr_is64 = self.rowptr.data_ptr(), int(self.rowptr.dtype == torch.int64)
-        p.long_thresh = self.long_thresh if self.long_thresh > 0 else \
-            _native.GCN_DEFAULT_LONG_THRESH
+        p.long_thresh = thresh
         p.col, p.val = self.col.data_ptr(), self.val.data_ptr()
         p.n_items, p.items = ni, keep["items"].data_ptr()
         p.n_chunks, p.chunk_row, p.chunk_e0 = nc, keep["chunk_row"].data_ptr(), \
             keep["chunk_e0"].data_ptr()
         p.n_long, p.long_row, p.long_chunk0 = nl, keep["long_row"].data_ptr(), \
             keep["long_chunk0"].data_ptr()
-        self._plan = p
         return p
 
-    def _plan_arrays_device(self):
+    def _plan_arrays_device(self, long_thresh):
         L = _native.lib()
         dev, n_rows = self.device, self.shape[0]
         is64 = int(self.rowptr.dtype == torch.int64)
@@ -243,7 +260,7 @@ class CSRGraph:
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             _native.check(L.gcn_plan_count_device(self.rowptr.data_ptr(), is64, n_rows,
-                                                  self.item_cost, self.long_thresh, ws.data_ptr(),
+                                                  self.item_cost, long_thresh, ws.data_ptr(),
                                                   ws_bytes, counts.data_ptr(), stream),
                           "gcn_plan_count_device")
             ni, nc, nl = (int(v) for v in counts.tolist())
@@ -254,7 +271,7 @@ class CSRGraph:
                     "long_chunk0": torch.empty(nl + 1, dtype=torch.int32, device=dev),
                     "n_items": ni, "n_chunks": nc, "n_long": nl}
             _native.check(L.gcn_plan_fill_device(
-                self.rowptr.data_ptr(), is64, n_rows, self.long_thresh, ws.data_ptr(), ws_bytes,
+                self.rowptr.data_ptr(), is64, n_rows, long_thresh, ws.data_ptr(), ws_bytes,
                 keep["items"].data_ptr(), ni, keep["chunk_row"].data_ptr(),
                 keep["chunk_e0"].data_ptr(), nc, keep["long_row"].data_ptr(),
                 keep["long_chunk0"].data_ptr(), nl, stream), "gcn_plan_fill_device")

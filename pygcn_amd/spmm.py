@@ -103,7 +103,7 @@ def spmm_csr(graph, B, bias=None, relu=False, out=None, tag="fwd", dropout_p=0.0
         if bias.numel() != F:
             raise RuntimeError("bias must have F entries")
     L = _native.lib()
-    plan = graph.plan()
+    plan = graph.plan(B.dtype)
     ws_bytes = L.gcn_spmm_workspace_bytes(plan, F)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=B.device) if ws_bytes else None
     with torch.cuda.device(B.device):

@@ -14,6 +14,7 @@ stated; device-side twins live in gcn_spmm.hip (`use_row_flags`).
 | REASSOC_MAX_WIDTH_RATIO | 2 | first layer as (Â·X)·W (or the restricted product (Â·X)[R2]) only while Fin ≤ 2·Fout | the product gathers rows of width Fin instead of Fout: at 1433 → 16 (Cora) the transpose product is 90× cheaper |
 | MIN_ROWS | 2¹⁷ | row compaction / K-split weight gradient only from this many vertices | below ≈ 10⁵ rows every GEMM of the step is launch-bound (≤ 20 µs): C2 / C3-sized probes |
 | K_SPLIT | 128 | slabs of the hipBLASLt weight-gradient fallback | `tools/gemm_probe.py`: 8.7 ms vs 21.5 ms stream-K at N = 10⁷ |
+| LONG_THRESH_BF16 | 1 024 | chunk length of long rows when the dense operand is stored in bf16 (fp32 storage keeps the C-ABI default, 256: the sequential fp32 chain of a chunk bounds the rounding error of the 1e-5 contract — at 1 024 the Â·1 = 1 residual at C4 is 1.4·10⁻⁵) | C5 forward product 41.5 → 38.9–39.7 ms (`bench.py --config c5 --spmm-only --long-thresh …`: 512: 39.9–40.3, 2 048: 39.3, 16 384: 39.2): 4× fewer chunk partials (1.7 GB of fp32 slabs written and re-read at 256) and long rows (7.4·10⁵ at 256); bf16 storage rounds to 2⁻⁸ anyway |
 | ROWGRAD_MIN_ROWS | 16 384 | `model(x, adj)` runs as one autograd node and returns a RowSelectable (structural `output[idx]` gradient) from this many vertices; below, the plain layer-by-layer composition | Cora-sized epochs are launch-bound (C2: 0.85 ms layer-by-layer against 1.04 ms through the node's generic fallbacks for 1433 → 16 → 7); the wrapper subclass costs ≈ 30 µs of dispatch |
 """
 from fractions import Fraction
@@ -26,6 +27,7 @@ REASSOC_MAX_WIDTH_RATIO = 2
 MIN_ROWS = 1 << 17
 K_SPLIT = 128
 ROWGRAD_MIN_ROWS = 16384
+LONG_THRESH_BF16 = 1024
 
 
 def below(count, total, share):

@@ -1280,3 +1280,33 @@ def test_rows_pack_rejects_unsupported_shapes(dev):
         rows_pack(torch.zeros((4, 64)))                          # host tensor: no CPU path
     with pytest.raises(RuntimeError):
         rows_unpack(torch.zeros((4, 2), dtype=torch.int32, device=dev), torch.zeros(0, device=dev), 96)
+
+
+def test_long_row_chunk_length_follows_the_storage_type(oracle, dev):
+    """A graph built without an explicit `long_thresh` chunks long rows at the C-ABI default (256:
+    the sequential fp32 chain of a chunk bounds the rounding error of the 1e-5 contract) for fp32
+    operands and at tuning.LONG_THRESH_BF16 (1 024) for bf16 storage — a second cached schedule;
+    an explicit `long_thresh` is honoured for every type.  Same bits as a graph built with that
+    chunk length explicitly; both chunk lengths agree to bf16 resolution."""
+    from pygcn_amd import spmm_csr, tuning, _native
+    n, F = 4000, 128
+    a = _skewed_csr(oracle, n, n, 6, seed=41, hubs=((5, 3000), (1700, 1500), (2500, 700)), empties=30)
+    g = _graph(a, dev)
+    assert g.plan().long_thresh == _native.GCN_DEFAULT_LONG_THRESH == 256
+    assert g.plan(torch.float32).long_thresh == 256
+    pb = g.plan(torch.bfloat16)
+    assert pb.long_thresh == tuning.LONG_THRESH_BF16 == 1024 and pb is g.plan(torch.bfloat16)
+    assert 0 < pb.n_long < g.plan().n_long and pb.n_chunks < g.plan().n_chunks
+    B = torch.from_numpy(gin.dense((n, F), 7)).to(dev)
+    bias = torch.from_numpy(gin.dense((F,), 8)).to(dev)
+    got = spmm_csr(g, B.bfloat16(), bias=bias, log_softmax=True)
+    g1024, g256 = _graph(a, dev, long_thresh=1024), _graph(a, dev, long_thresh=256)
+    assert g256.plan(torch.bfloat16).long_thresh == 256
+    assert torch.equal(got, spmm_csr(g1024, B.bfloat16(), bias=bias, log_softmax=True))
+    other = spmm_csr(g256, B.bfloat16(), bias=bias, log_softmax=True)
+    assert (got.float() - other.float()).abs().max().item() <= 2.0 ** -7 * other.float().abs().max().item()
+    ref, _ = oracle.gc_forward(B.bfloat16().float().cpu().numpy(), np.eye(F, dtype=np.float32), bias.cpu().numpy(), a)
+    ref = ref - np.log(np.exp(ref - ref.max(1, keepdims=True)).sum(1, keepdims=True)) - ref.max(1, keepdims=True)
+    assert_normwise(got.float().cpu(), ref, 2.0 ** -7, "bf16 product with 1 024-entry chunks")
+    # fp32 keeps the default schedule
+    assert torch.equal(spmm_csr(g, B), spmm_csr(g256, B))
