@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 23
+#define GCN_ABI_VERSION 24
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -72,7 +72,10 @@ typedef struct gcn_csr_plan {
     const int32_t *long_chunk0;/* [n_long+1] first chunk of every long row                   */
 } gcn_csr_plan;
 
-/* ABI history: 21 = round 2's surface.  23 (round 3, late): at p = 1/2 the dropout keep function
+/* ABI history: 21 = round 2's surface.  24 (round 4): new entry points gcn_gemm_xw256_f32_b3 /
+ * gcn_gemm_atg256_f32_b3 (the fp32-EQUIVALENT three-part bf16 form of the 256-wide GEMMs with the
+ * full option set of the _h2 entry points: row lists, forward epilogue, backward mask, max|Y|) and
+ * gcn_gemm_xw256_b3_workspace_bytes; nothing existing changed.  23 (round 3, late): at p = 1/2 the dropout keep function
  * draws 128 one-bit fields per Philox call (other p unchanged) — masks at p = 1/2 differ from ABI
  * 22's; no signature or struct changed.  22 (round 3): the dropout keep function draws eight 16-bit
  * fields per Philox call instead of four 32-bit words and takes a row base (drop_row_base in both
@@ -418,6 +421,21 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
                           size_t workspace_bytes, void *stream);
 
 /*
+ * The fp32-EQUIVALENT form of the same product (ABI 24) — what `torch.mm(input, self.weight)`
+ * (pygcn/layers.py:33) computes in fp32: both operands split into THREE bf16 parts (a 24-bit
+ * significand, fp32's own), six bf16 MFMAs per product (every term down to 2^-16 of the leading
+ * one; the dropped ones are <= 2^-24), fp32 accumulation.  bf16 has fp32's exponent range: no
+ * scaling and no bound.  Same kernel pipeline and the same options as gcn_gemm_xw256_f32_h2 — x_rows,
+ * y_absmax, the whole struct gcn_gemm_epilogue — and bit-identical results to gcn_gemm_xw256_f32
+ * for the plain product.  Workspace >= gcn_gemm_xw256_b3_workspace_bytes().
+ */
+size_t gcn_gemm_xw256_b3_workspace_bytes(void);
+int gcn_gemm_xw256_f32_b3(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                          int64_t ldw, float *Y, int64_t ldy, int64_t M, float *y_absmax,
+                          const gcn_gemm_epilogue *epilogue, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/*
  * Y[M, N] = X[M, K] · W[K, N] for bf16 storage (config C5: 128 -> 128): bf16 in / out, fp32
  * accumulate, (K, N) one of (128,128), (128,256), (256,128).  HBM-bound by construction (W resident in LDS, X streamed
  * once, Y written once as 16-byte stores).  `torch.mm(input, weight)` (pygcn/layers.py:33) and
@@ -449,6 +467,11 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
                         const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
                         const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* The fp32-equivalent form (ABI 24): three bf16 parts per operand, six MFMAs per product, no
+ * bounds (see gcn_gemm_xw256_f32_b3); same lists, workspace and determinism. */
+int gcn_gemm_atg256_f32_b3(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                           const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /*
  * The same weight gradient for bf16 STORAGE (config C5: 128 -> 128 layers): A [*, K] and G [*, N]

@@ -209,6 +209,20 @@ def gc_backward(x, weight, has_bias, adj, grad_out, need_grad_x=True):
     return grad_x, grad_w, grad_bias, grad_support
 
 
+def gc_backward_f64(x, weight, has_bias, adj, grad_out, need_grad_x=True):
+    """gc_backward (autograd of layers.py:32-38) evaluated in FLOAT64 on the same float32 inputs:
+    the arbiter for gradients that are float32 reductions over the graph's vertices, where the
+    float32 reference arithmetic itself is ~1e-5 from exact (tests/conftest.py assert_parity).
+    Returns (grad_x, grad_w, grad_bias)."""
+    A = sp.csr_matrix((adj.val.astype(np.float64), adj.col, adj.rowptr), shape=adj.shape)
+    g = np.asarray(grad_out, np.float64)
+    grad_bias = g.sum(0) if has_bias else None
+    grad_support = A.T.tocsr() @ g
+    grad_w = np.asarray(x, np.float64).T @ grad_support
+    grad_x = grad_support @ np.asarray(weight, np.float64).T if need_grad_x else None
+    return grad_x, grad_w, grad_bias
+
+
 # --------------------------------------------------------------------------- upstream 2-layer GCN
 def log_softmax(z):
     m = z.max(1, keepdims=True)

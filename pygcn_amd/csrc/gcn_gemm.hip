@@ -330,6 +330,23 @@ constexpr int kXChunkBytes = 4 * kXInstrBytes;            // 32 rows x 32 column
 constexpr int kXRing = 2;                                  // chunks per wave: one in use, one in flight
 constexpr int kXLdsBytes = GEMM_H2_XLDS ? kWaves * kXRing * kXChunkBytes : 0;
 
+// The two decompositions the product kernel is instantiated for (template parameter SCH):
+//   0 "h2": two fp16 parts of both operands after an exact power-of-two scaling, 3 MFMAs per product
+//           (22-bit significand; needs an upper bound of max|X|);
+//   1 "b3": three bf16 parts, 6 MFMAs per product, no scaling and no bound — a 24-bit significand,
+//           the fp32-equivalent form of `torch.mm(input, self.weight)` (pygcn/layers.py:33).
+// Same pipeline (persistent workgroups, X and W by HBM -> LDS DMA, cross-tile prefetch, compile-time
+// store sections); b3's W stage is ONE K step (24 KiB: three parts x 8 column blocks) so that two
+// stages + the X rings fit the 160 KiB of LDS — its 48 MFMAs per barrier equal h2's 2 x 24.
+template <int SCH> struct SchemeK {
+    static constexpr int NS = SCH == 0 ? 2 : 3;                    // parts per operand
+    static constexpr int KS = SCH == 0 ? kStage : 1;               // K steps of W per LDS stage (= per barrier)
+    static constexpr int ChunkBytes = NS * 8 * kFragBytes;         // one K step of W: 16 / 24 KiB
+    static constexpr int StageBytes = KS * ChunkBytes;             // 32 / 24 KiB
+    static constexpr int WShare = StageBytes / kWaves;             // a wave's part of a stage: 4 / 3 KiB
+};
+static_assert(SchemeK<0>::StageBytes == 2 * 8 * kFragBytes * kStage, "h2 stage");
+
 // exponent e with 2^e <= v < 2^(e+1) for finite v > 0 (0 for zero / non-finite: no scaling)
 __device__ __forceinline__ int floor_log2f(float v)
 {
@@ -464,12 +481,16 @@ template <int N> __device__ __forceinline__ void dma_wait()
 // they cost one drain of all earlier stores per column block); both persistent with the cross-tile pipeline.
 // EPI 1 (FWD_EPI): bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
 // the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
-template <int EPI>
+template <int EPI, int SCH = 0>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
     const unsigned char *__restrict__ ws, const float *__restrict__ x_bound, float *__restrict__ Y,
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
+    // SCH: 0 two scaled fp16 parts (x_bound required), 1 three bf16 parts (x_bound unused) — SchemeK
+    typedef SchemeK<SCH> SK;
+    constexpr int NS = SK::NS, KS = SK::KS, kSchChunkBytes = SK::ChunkBytes, kSchStageBytes = SK::StageBytes;
+    static_assert(SCH == 0 || GEMM_H2_XLDS, "the three-part scheme exists in the DMA pipeline only");
     // EPI: 0 plain, 2 backward mask; forward epilogues (bias always, zeros when there is none):
     // 1 bias only, 4 + ReLU, 5 + ReLU + dropout at p = 1/2 (one-bit keep fields), 6 + ReLU + dropout
     // at any other p (16-bit fields).  Compile-time options: a uniform branch per column group in
@@ -486,8 +507,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // workgroup per CU nothing else would cover it).  The X ring has kH2Ring slots with static
     // indices; kChunks % kH2Ring == 0 keeps slot = step % kH2Ring valid across the boundary.
     static_assert(kChunks % kH2Ring == 0, "the X ring must divide the K steps of a tile");
-    static_assert(kChunks % kStage == 0 && (kChunks / kStage) % 2 == 0, "W stages must alternate evenly");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kH2StageBytes];     // the two W stages
+    static_assert(kChunks % KS == 0 && (kChunks / KS) % 2 == 0, "W stages must alternate evenly");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSchStageBytes];    // the two W stages
 #if GEMM_H2_XLDS
     // (a separate LDS object, so the compiler's wait-count pass can tell a DMA into an X ring from
     //  a store into a W stage and does not drain the X prefetch at every W stage)
@@ -514,35 +535,40 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         __syncthreads();
     }
 
-    // scales (wave-uniform scalars)
-    int x_exp = 14 - floor_log2f(*x_bound);
-    x_exp = x_exp > 126 ? 126 : (x_exp < -126 ? -126 : x_exp);
-    bool poisoned = false;
-    {
-        const float b = *x_bound;
-        if (!(b > 0.f)) x_exp = 0;                    // zero bound (an all-zero operand): no scaling
-        // A bound that is inf / NaN is the sentinel of an overflow upstream (y_absmax of a launch
-        // whose own bound was too small): it must not turn into silent zeros — poison the result.
-        poisoned = !(b <= 3.4028235e38f);
-        if (poisoned) x_exp = 0;
+    // scales (wave-uniform scalars; the three-part bf16 scheme has fp32's range and needs none)
+    float xs = 1.f, back_a = 1.f, back_b = 1.f;
+    bool one_step = true;
+    if constexpr (SCH == 0) {
+        int x_exp = 14 - floor_log2f(*x_bound);
+        x_exp = x_exp > 126 ? 126 : (x_exp < -126 ? -126 : x_exp);
+        bool poisoned = false;
+        {
+            const float b = *x_bound;
+            if (!(b > 0.f)) x_exp = 0;                    // zero bound (an all-zero operand): no scaling
+            // A bound that is inf / NaN is the sentinel of an overflow upstream (y_absmax of a launch
+            // whose own bound was too small): it must not turn into silent zeros — poison the result.
+            poisoned = !(b <= 3.4028235e38f);
+            if (poisoned) x_exp = 0;
+        }
+        xs = pow2f(x_exp);
+        const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
+        // (one multiply when 2^back is a normal float — always, outside the edges of fp32 —, else two)
+        one_step = back >= -126 && back <= 127;
+        back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(one_step ? back : back / 2);
+        back_b = one_step ? 1.f : pow2f(back - back / 2);    // exact steps
     }
-    const float xs = pow2f(x_exp);
-    const int back = -(x_exp + ((const H2Header *)ws)->w_exp);       // result * 2^back, in two
-    // (one multiply when 2^back is a normal float — always, outside the edges of fp32 —, else two)
-    const bool one_step = back >= -126 && back <= 127;
-    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(one_step ? back : back / 2);
-    const float back_b = one_step ? 1.f : pow2f(back - back / 2);    // exact steps
 
 #if GEMM_H2_XLDS
     static_assert(kStage == 2 && kWaves == 8, "the DMA pipeline is written for 2-step W stages and 8 waves");
+    static_assert(SK::WShare % 1024 == 0, "a wave's part of a W stage is whole DMA instructions");
     const unsigned char *wl = wimg;
     const uint32_t w_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds +
-                           __builtin_amdgcn_readfirstlane(wave) * (kH2StageBytes / kWaves);
-    // this wave's eighth (4 KiB = 4 DMA instructions) of W stage `st` -> W buffer `b`
+                           __builtin_amdgcn_readfirstlane(wave) * SK::WShare;
+    // this wave's eighth (h2: 4 KiB = 4 DMA instructions, b3: 3) of W stage `st` -> W buffer `b`
     auto w_issue = [&](int st, int b) {
-        const unsigned char *src = wl + (size_t)st * kH2StageBytes + wave * (kH2StageBytes / kWaves) + lane * 16;
+        const unsigned char *src = wl + (size_t)st * kSchStageBytes + wave * SK::WShare + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(src + i * 1024, w_lds + b * kH2StageBytes + i * 1024);
+        for (int i = 0; i < SK::WShare / 1024; ++i) dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
     };
 #else
     u32x4 wreg[kH2WLoads];
@@ -592,9 +618,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     };
 #endif
     u32x4 Ah, Am;
+    [[maybe_unused]] u32x4 Al;                     // (third part: SCH 1 only)
     auto split_frag = [&](const f32x4 &lo, const f32x4 &hi, bool ok) {
         const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         uint32_t h[4], m[4];
+        if constexpr (SCH == 1) {
+            uint32_t l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                split3_pair(ok ? av[2 * j] : 0.f, ok ? av[2 * j + 1] : 0.f, h[j], m[j], l[j]);
+            Ah = u32x4{h[0], h[1], h[2], h[3]};
+            Am = u32x4{m[0], m[1], m[2], m[3]};
+            Al = u32x4{l[0], l[1], l[2], l[3]};
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x0 = ok ? av[2 * j] * xs : 0.f, x1 = ok ? av[2 * j + 1] * xs : 0.f;
@@ -683,13 +720,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
-            const int st = c / kStage;
+            const int st = c / KS;
 #if GEMM_H2_XLDS
-            if (c % kStage == 0) {
+            if (c % KS == 0) {
                 // every wave waited for ITS part of W stage st before it got here (end of the
                 // previous stage / prologue) and has read its last fragment of stage st - 1
                 __builtin_amdgcn_s_barrier();
-                if ((st + 1) * kStage < kChunks)
+                if ((st + 1) * KS < kChunks)
                     w_issue(st + 1, (st + 1) & 1);
                 else if (has_next)
                     w_issue(0, 0);                                // the next tile's first stage
@@ -725,11 +762,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             }
 #endif
             const u32x4 Xh = Ah, Xm = Am;
-            const unsigned char *buf = lds + (st & 1) * kH2StageBytes + (c % kStage) * kH2ChunkBytes;
-            u32x4 Bf[2][2];
-            auto b_read = [&](int nb, u32x4 (&dst)[2]) {
-                dst[0] = *(const u32x4 *)(buf + ((0 * 8 + nb) * 64 + lane) * 16);
-                dst[1] = *(const u32x4 *)(buf + ((1 * 8 + nb) * 64 + lane) * 16);
+            [[maybe_unused]] const u32x4 Xl = Al;
+            const unsigned char *buf = lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
+            u32x4 Bf[2][NS];
+            auto b_read = [&](int nb, u32x4 (&dst)[NS]) {
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) dst[sp] = *(const u32x4 *)(buf + ((sp * 8 + nb) * 64 + lane) * 16);
             };
             b_read(0, Bf[0]);
 #pragma unroll
@@ -738,19 +776,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
                 f32x16 t = acc[nb];
                 __builtin_amdgcn_s_setprio(1);
-                t = mfma_h(Bm, Xh, t);       // smaller terms first
-                t = mfma_h(Bh, Xm, t);
-                t = mfma_h(Bh, Xh, t);
+                if constexpr (SCH == 1) {
+                    // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
+                    const u32x4 Bl = Bf[nb & 1][NS - 1];
+                    t = mfma(Bh, Xl, t);
+                    t = mfma(Bl, Xh, t);
+                    t = mfma(Bm, Xm, t);
+                    t = mfma(Bh, Xm, t);
+                    t = mfma(Bm, Xh, t);
+                    t = mfma(Bh, Xh, t);
+                } else {
+                    t = mfma_h(Bm, Xh, t);       // smaller terms first
+                    t = mfma_h(Bh, Xm, t);
+                    t = mfma_h(Bh, Xh, t);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 acc[nb] = t;
             }
 #if GEMM_H2_XLDS
-            if (c % kStage == kStage - 1) {
-                // before the next stage: this wave's part of W stage st + 1 and X chunk st + 1 (the
-                // next K step's fragment) must be in LDS.  Younger than both: only the 4 DMA
-                // instructions of X chunk st + 2, issued at the top of this step — if they were.
+            if (c % KS == KS - 1) {
+                // before the next stage: this wave's part of W stage st + 1 and the X chunk of the
+                // next K step must be in LDS.  Younger than both: only the 4 DMA instructions of an
+                // X chunk issued at the top of THIS step (odd steps) — if they were.  (b3, one-step
+                // stages: on even steps the W stage just issued is the youngest — a full wait, 48
+                // MFMAs after its issue, the flight time h2's stages have too.)
                 constexpr int kCh = kChunks / 2;
-                const bool issued_x = ((c + 3) / 2 < kCh) || has_next;
+                const bool issued_x = (c & 1) && (((c + 3) / 2 < kCh) || has_next);
                 if (c + 1 < kChunks || has_next) {
                     if (issued_x) dma_wait<4>();
                     else dma_wait<0>();
@@ -770,7 +821,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 f32x4 lo, hi;
                 a_read(cn & 1, (cn >> 1) & 1, lo, hi);
                 split_frag(lo, hi, c + 1 < kChunks ? row_ok : ok_n);
-                asm volatile("" : "+v"(Ah), "+v"(Am));
+                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
+                else asm volatile("" : "+v"(Ah), "+v"(Am));
             }
 #else
             if (c + 1 < kChunks) {
@@ -832,10 +884,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[nb][4 * g] * back_a, acc[nb][4 * g + 1] * back_a,
-                               acc[nb][4 * g + 2] * back_a, acc[nb][4 * g + 3] * back_a};
-                    if (!one_step) {                                           // (wave-uniform, rare)
-                        v.x *= back_b; v.y *= back_b; v.z *= back_b; v.w *= back_b;
+                    f32x4 v = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
+                    if constexpr (SCH == 0) {                                  // undo the operand scaling
+                        v.x *= back_a; v.y *= back_a; v.z *= back_a; v.w *= back_a;
+                        if (!one_step) {                                       // (wave-uniform, rare)
+                            v.x *= back_b; v.y *= back_b; v.z *= back_b; v.w *= back_b;
+                        }
                     }
                     // forward epilogue of the layer when the GEMM is its LAST stage
                     // ((Â·X)·W + b, pygcn/layers.py:33-36 reassociated): bias, ReLU, inverted dropout
@@ -1205,8 +1259,14 @@ __global__ __launch_bounds__(256) void order_w_bf16_kernel(const uint16_t *__res
 constexpr int kAtgSuperMin = 4;                 // at least this many 32-row super-steps per workgroup
 constexpr int kAtgMaxWgs = 256;
 constexpr int kAtgDepth = 2;
-constexpr int kAtgBufBytes = 2 * 2 * 8 * 2 * kFragBytes;   // [operand][MFMA step][tile][split] = 64 KiB
+constexpr int kAtgBufBytes = 2 * 2 * 8 * 2 * kFragBytes;   // [operand][MFMA step][tile][split] = 64 KiB (h2)
+// SCH (SchemeK): 0 two scaled fp16 parts, two LDS buffers (one barrier per super-step); 1 three bf16
+// parts — the fp32-equivalent form, no bounds: its 96 KiB of fragments per super-step exist ONCE
+// (two buffers would not fit the LDS), so a second barrier separates multiply and publish.
+template <int SCH> constexpr int atg_buf_bytes() { return 2 * 2 * 8 * SchemeK<SCH>::NS * kFragBytes; }
+template <int SCH> constexpr int atg_lds_bytes() { return (SCH == 0 ? 2 : 1) * atg_buf_bytes<SCH>(); }
 
+template <int SCH>
 __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
     const float *__restrict__ G, int64_t ldg, const int32_t *__restrict__ rg, int64_t n_list,
@@ -1223,13 +1283,17 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
         e = e > 126 ? 126 : (e < -126 ? -126 : e);
         return (!(b > 0.f) || !(b <= 3.4028235e38f)) ? 0 : e;
     };
-    const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
-    const float my_scale = pow2f(op ? g_exp : a_exp);
-    const int back = -(a_exp + g_exp);
-    // (an inf / NaN bound = an overflow upstream: poison the result instead of scaling by 1)
-    const bool poisoned = !(*a_bound <= 3.4028235e38f) || !(*g_bound <= 3.4028235e38f);
-    const float back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
-    const float back_b = pow2f(back - back / 2);
+    constexpr int NS = SchemeK<SCH>::NS;
+    float my_scale = 1.f, back_a = 1.f, back_b = 1.f;
+    if constexpr (SCH == 0) {
+        const int a_exp = scale_exp(*a_bound), g_exp = scale_exp(*g_bound);
+        my_scale = pow2f(op ? g_exp : a_exp);
+        const int back = -(a_exp + g_exp);
+        // (an inf / NaN bound = an overflow upstream: poison the result instead of scaling by 1)
+        const bool poisoned = !(*a_bound <= 3.4028235e38f) || !(*g_bound <= 3.4028235e38f);
+        back_a = poisoned ? __uint_as_float(0x7fc00000u) : pow2f(back / 2);
+        back_b = pow2f(back - back / 2);
+    }
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -1278,24 +1342,30 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
             x[j][3] = live ? v[j].w * my_scale : 0.f;
         }
         // fragment lane: this lane's column slot in the k-half this wave loads; tiles 2q + (lane >> 5)
-        unsigned char *mine = buf + ((size_t)((op * 2 + (w8 >> 1)) * 8 + (lane >> 5)) * 2) * kFragBytes +
+        unsigned char *mine = buf + ((size_t)((op * 2 + (w8 >> 1)) * 8 + (lane >> 5)) * NS) * kFragBytes +
                               ((lane & 31) + 32 * (w8 & 1)) * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t hh[4], mm[4];
+            [[maybe_unused]] uint32_t ll[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x2 p = {x[2 * j][q], x[2 * j + 1][q]};
-                const h16x2 ph = __builtin_convertvector(p, h16x2);
-                const f32x2 pb = __builtin_convertvector(ph, f32x2);
-                f32x2 r = {p.x - pb.x, p.y - pb.y};
-                const h16x2 pm = __builtin_convertvector(r, h16x2);
-                hh[j] = __builtin_bit_cast(uint32_t, ph);
-                mm[j] = __builtin_bit_cast(uint32_t, pm);
+                if constexpr (SCH == 1) {
+                    split3_pair(x[2 * j][q], x[2 * j + 1][q], hh[j], mm[j], ll[j]);
+                } else {
+                    f32x2 p = {x[2 * j][q], x[2 * j + 1][q]};
+                    const h16x2 ph = __builtin_convertvector(p, h16x2);
+                    const f32x2 pb = __builtin_convertvector(ph, f32x2);
+                    f32x2 r = {p.x - pb.x, p.y - pb.y};
+                    const h16x2 pm = __builtin_convertvector(r, h16x2);
+                    hh[j] = __builtin_bit_cast(uint32_t, ph);
+                    mm[j] = __builtin_bit_cast(uint32_t, pm);
+                }
             }
-            unsigned char *tile = mine + (size_t)(2 * q) * 2 * kFragBytes;       // tile 2q + (lane >> 5)
+            unsigned char *tile = mine + (size_t)(2 * q) * NS * kFragBytes;      // tile 2q + (lane >> 5)
             *(u32x4 *)(tile) = u32x4{hh[0], hh[1], hh[2], hh[3]};
             *(u32x4 *)(tile + kFragBytes) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+            if constexpr (SCH == 1) *(u32x4 *)(tile + 2 * kFragBytes) = u32x4{ll[0], ll[1], ll[2], ll[3]};
         }
     };
 
@@ -1311,34 +1381,46 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
 #pragma unroll
             for (int d = 0; d < kAtgDepth; ++d) {
                 const int64_t ss = base + d;                     // (ss >= s1 in the last pass: zeros)
-                unsigned char *buf = lds + (int)((ss - s0) & 1) * kAtgBufBytes;
+                unsigned char *buf = lds + (SCH == 0 ? (int)((ss - s0) & 1) * atg_buf_bytes<SCH>() : 0);
                 // (a scheduling fence: the arithmetic of THIS super-step's publish must not move up
                 //  into the previous one — it would wait there for loads that are one step younger)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SCH == 1) __syncthreads();     // (one buffer: everyone has multiplied the previous super-step)
                 publish(ss, ring[d], buf);
                 if (!(ATG_ABLATE & 4)) fetch(ss + kAtgDepth, ring[d]);
                 __syncthreads();
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const unsigned char *ab = buf + (size_t)((0 * 2 + s2) * 8) * 2 * kFragBytes;
-                    const unsigned char *gbase = buf + (size_t)((1 * 2 + s2) * 8) * 2 * kFragBytes;
-                    u32x4 Af[2][2];
+                    const unsigned char *ab = buf + (size_t)((0 * 2 + s2) * 8) * NS * kFragBytes;
+                    const unsigned char *gbase = buf + (size_t)((1 * 2 + s2) * 8) * NS * kFragBytes;
+                    u32x4 Af[2][NS];
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                        for (int sp = 0; sp < 2; ++sp)
-                            Af[ib][sp] = *(const u32x4 *)(ab + (((2 * iw + ib) * 2 + sp) * 64 + lane) * 16);
+                        for (int sp = 0; sp < NS; ++sp)
+                            Af[ib][sp] = *(const u32x4 *)(ab + (((2 * iw + ib) * NS + sp) * 64 + lane) * 16);
 #pragma unroll
                     for (int jb = 0; jb < 4; ++jb) {
-                        const unsigned char *gb = gbase + ((4 * jh + jb) * 2) * kFragBytes;
+                        const unsigned char *gb = gbase + ((4 * jh + jb) * NS) * kFragBytes;
                         const u32x4 Bh = *(const u32x4 *)(gb + (0 * 64 + lane) * 16);
                         const u32x4 Bm = *(const u32x4 *)(gb + (1 * 64 + lane) * 16);
+                        [[maybe_unused]] u32x4 Bl;
+                        if constexpr (SCH == 1) Bl = *(const u32x4 *)(gb + (2 * 64 + lane) * 16);
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) {
                             f32x16 t = acc[ib][jb];
-                            t = mfma_h(Af[ib][1], Bh, t);
-                            t = mfma_h(Af[ib][0], Bm, t);
-                            t = mfma_h(Af[ib][0], Bh, t);
+                            if constexpr (SCH == 1) {          // smallest terms first
+                                t = mfma(Af[ib][0], Bl, t);
+                                t = mfma(Af[ib][2], Bh, t);
+                                t = mfma(Af[ib][1], Bm, t);
+                                t = mfma(Af[ib][0], Bm, t);
+                                t = mfma(Af[ib][1], Bh, t);
+                                t = mfma(Af[ib][0], Bh, t);
+                            } else {
+                                t = mfma_h(Af[ib][1], Bh, t);
+                                t = mfma_h(Af[ib][0], Bm, t);
+                                t = mfma_h(Af[ib][0], Bh, t);
+                            }
                             acc[ib][jb] = t;
                         }
                     }
@@ -1360,7 +1442,7 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
             for (int reg = 0; reg < 16; ++reg) {
                 const int i = (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const int row = 128 * (ta & 1) + 4 * i + (ta >> 1);
-                out[row * kN + col] = acc[ib][jb][reg] * back_a * back_b;
+                out[row * kN + col] = SCH == 0 ? acc[ib][jb][reg] * back_a * back_b : acc[ib][jb][reg];
             }
         }
 }
@@ -1567,11 +1649,20 @@ size_t gcn_gemm_xw256_h2_workspace_bytes(void)
     return (size_t)kH2HeaderBytes + (size_t)kChunks * kH2ChunkBytes;
 }
 
-int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
-                          int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
-                          float *y_absmax, const gcn_gemm_epilogue *epi, void *workspace,
-                          size_t workspace_bytes, void *stream)
+size_t gcn_gemm_xw256_b3_workspace_bytes(void)
 {
+    return (size_t)kH2HeaderBytes + (size_t)kChunks * SchemeK<1>::ChunkBytes;
+}
+
+}   // extern "C"
+
+// both decompositions of the 256 x 256 product (sch 0: two scaled fp16 parts, 1: three bf16 parts)
+static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                        int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
+                        float *y_absmax, const gcn_gemm_epilogue *epi, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    (void)who;
     const float *mask_src = epi ? epi->mask_src : nullptr;
     const int64_t ld_mask = epi ? epi->ld_mask : 0;
     H2Epi ep = {};
@@ -1598,9 +1689,10 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
     if (M == 0) return 0;
-    if (X == nullptr || W == nullptr || Y == nullptr || workspace == nullptr || x_absmax_bound == nullptr)
+    if (X == nullptr || W == nullptr || Y == nullptr || workspace == nullptr ||
+        (sch == 0 && x_absmax_bound == nullptr))
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: NULL pointer");
-    if (workspace_bytes < gcn_gemm_xw256_h2_workspace_bytes())
+    if (workspace_bytes < (sch == 0 ? gcn_gemm_xw256_h2_workspace_bytes() : gcn_gemm_xw256_b3_workspace_bytes()))
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_xw256_f32_h2: workspace too small");
     if ((((uintptr_t)X) | ((uintptr_t)Y) | ((uintptr_t)workspace)) % 16 != 0 || (ldx % 4) != 0 ||
         (ldy % 4) != 0 || (((uintptr_t)x_absmax_bound) | ((uintptr_t)y_absmax)) % 4 != 0 ||
@@ -1608,7 +1700,11 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
         ((uintptr_t)ep.bias) % 16 != 0)
         return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32_h2: X / Y rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
+    if (sch == 0)
+        hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
+    else      // (the three-part image of gemm_xw256_kernel, behind the same header space)
+        hipLaunchKernelGGL(split_w_kernel, dim3(kChunks * 8 * 64 / 256), dim3(256), 0, s, W, ldw,
+                           (uint16_t *)((unsigned char *)workspace + kH2HeaderBytes));
     const int64_t tiles = (M + kTileRows - 1) / kTileRows;
     // dynamic LDS of the X-through-LDS build: the two W stages + every wave's X ring (> 64 KiB)
     const size_t dyn = GEMM_H2_XLDS ? (size_t)kXLdsBytes : 0;
@@ -1617,7 +1713,10 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
         if (!raised) {
             const void *all[] = {(const void *)gemm_xw256_h2_kernel<0>, (const void *)gemm_xw256_h2_kernel<1>,
                                  (const void *)gemm_xw256_h2_kernel<2>, (const void *)gemm_xw256_h2_kernel<4>,
-                                 (const void *)gemm_xw256_h2_kernel<5>, (const void *)gemm_xw256_h2_kernel<6>};
+                                 (const void *)gemm_xw256_h2_kernel<5>, (const void *)gemm_xw256_h2_kernel<6>,
+                                 (const void *)gemm_xw256_h2_kernel<0, 1>, (const void *)gemm_xw256_h2_kernel<1, 1>,
+                                 (const void *)gemm_xw256_h2_kernel<2, 1>, (const void *)gemm_xw256_h2_kernel<4, 1>,
+                                 (const void *)gemm_xw256_h2_kernel<5, 1>, (const void *)gemm_xw256_h2_kernel<6, 1>};
             for (const void *k : all) {
                 hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
                 if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_h2: LDS size");
@@ -1632,8 +1731,14 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
                              : (!ep.relu ? 1 : (ep.drop_thresh == 0u ? 4 : (ep.drop_thresh == 32768u ? 5 : 6)));
     const unsigned grid = (fwd && !GEMM_H2_EPI_PERSIST) ? (unsigned)tiles : (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
 #define GCN_LAUNCH_H2(V)                                                                             \
-    hipLaunchKernelGGL(gemm_xw256_h2_kernel<V>, dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows,  \
-                       (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep)
+    do {                                                                                             \
+        if (sch == 0)                                                                                \
+            hipLaunchKernelGGL((gemm_xw256_h2_kernel<V, 0>), dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows, \
+                               (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep); \
+        else                                                                                         \
+            hipLaunchKernelGGL((gemm_xw256_h2_kernel<V, 1>), dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows, \
+                               (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep); \
+    } while (0)
     switch (variant) {
     case 0: GCN_LAUNCH_H2(0); break;
     case 1: GCN_LAUNCH_H2(1); break;
@@ -1646,6 +1751,26 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_xw256_f32_h2 launch");
     return 0;
+}
+
+extern "C" {
+
+int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                          int64_t ldw, float *Y, int64_t ldy, int64_t M, const float *x_absmax_bound,
+                          float *y_absmax, const gcn_gemm_epilogue *epi, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    return xw256_launch("gcn_gemm_xw256_f32_h2", 0, X, ldx, x_rows, W, ldw, Y, ldy, M, x_absmax_bound, y_absmax,
+                        epi, workspace, workspace_bytes, stream);
+}
+
+int gcn_gemm_xw256_f32_b3(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,
+                          int64_t ldw, float *Y, int64_t ldy, int64_t M, float *y_absmax,
+                          const gcn_gemm_epilogue *epi, void *workspace, size_t workspace_bytes,
+                          void *stream)
+{
+    return xw256_launch("gcn_gemm_xw256_f32_b3", 1, X, ldx, x_rows, W, ldw, Y, ldy, M, nullptr, y_absmax, epi,
+                        workspace, workspace_bytes, stream);
 }
 
 size_t gcn_gemm_bf16_workspace_bytes(int64_t K, int64_t N)
@@ -1757,10 +1882,12 @@ size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list)
     return (size_t)atg_wgs(n_list) * (size_t)(kK * kN) * sizeof(float);
 }
 
-int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
-                        const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
-                        const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
-                        size_t workspace_bytes, void *stream)
+}   // extern "C"
+
+static int atg256_launch(int sch, const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                         const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
+                         const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
+                         size_t workspace_bytes, void *stream)
 {
     if (n_list < 0 || lda < kK || ldg < kN || ldo < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: bad sizes");
@@ -1770,8 +1897,8 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)kN * 4, kK, s);
         return e == hipSuccess ? 0 : gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32: memset");
     }
-    if (A == nullptr || G == nullptr || rows_a == nullptr || rows_g == nullptr ||
-        a_absmax_bound == nullptr || g_absmax_bound == nullptr || workspace == nullptr)
+    if (A == nullptr || G == nullptr || rows_a == nullptr || rows_g == nullptr || workspace == nullptr ||
+        (sch == 0 && (a_absmax_bound == nullptr || g_absmax_bound == nullptr)))
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL pointer");
     if (workspace_bytes < gcn_gemm_atg256_workspace_bytes(n_list))
         return gcn_internal_fail(GCN_E_WORKSPACE, "gcn_gemm_atg256_f32: workspace too small");
@@ -1783,19 +1910,45 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
     {
         static bool lds_set = false;
         if (!lds_set) {
-            hipError_t ae = hipFuncSetAttribute((const void *)gemm_atg256_h2_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kAtgBufBytes);
+            hipError_t ae = hipFuncSetAttribute((const void *)gemm_atg256_h2_kernel<0>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, atg_lds_bytes<0>());
+            if (ae == hipSuccess)
+                ae = hipFuncSetAttribute((const void *)gemm_atg256_h2_kernel<1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, atg_lds_bytes<1>());
             if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_atg256_f32: LDS size");
             lds_set = true;
         }
     }
-    hipLaunchKernelGGL(gemm_atg256_h2_kernel, dim3((unsigned)n_wg), dim3(512), 2 * kAtgBufBytes, s, A, lda, rows_a, G,
-                       ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
+    if (sch == 0)
+        hipLaunchKernelGGL(gemm_atg256_h2_kernel<0>, dim3((unsigned)n_wg), dim3(512), atg_lds_bytes<0>(), s, A, lda,
+                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
+    else
+        hipLaunchKernelGGL(gemm_atg256_h2_kernel<1>, dim3((unsigned)n_wg), dim3(512), atg_lds_bytes<1>(), s, A, lda,
+                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
     hipLaunchKernelGGL(atg_reduce_kernel, dim3(kK * kN / 256), dim3(256), 0, s, (const float *)workspace,
                        (int)n_wg, out, ldo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32 launch");
     return 0;
+}
+
+extern "C" {
+
+int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                        const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
+                        const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    return atg256_launch(0, A, lda, rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, out, ldo,
+                         workspace, workspace_bytes, stream);
+}
+
+int gcn_gemm_atg256_f32_b3(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                           const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    return atg256_launch(1, A, lda, rows_a, G, ldg, rows_g, n_list, nullptr, nullptr, out, ldo, workspace,
+                         workspace_bytes, stream);
 }
 
 static int64_t atg_bf16_wgs(int64_t n_list)

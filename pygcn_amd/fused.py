@@ -173,9 +173,10 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     Fills ctx.scale / x_bound / z_bound / h_bound / reassoc / has_bias / bias_dtypes."""
     ctx.graph = graph
     ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
-    # bounds of max|operand| for the scaled fp16 GEMM, without a pass over the data:
+    # bounds of max|operand| for the scaled fp16 GEMMs (set_gemm_scheme("h2") only; the default
+    # three-part bf16 GEMMs need none), without a pass over the data:
     # X is constant (cached), and |Â·B| <= ‖Â‖∞·max|B|
-    bounded = x.dtype == torch.float32
+    bounded = x.dtype == torch.float32 and _spmm.gemm_needs_bounds()
     ctx.x_bound = _spmm.absmax_cached(x) if bounded else None
     # Layer 1 REASSOCIATED when a GEMM kernel can carry the layer's epilogue (256 -> 256 fp32;
     # bf16 128 -> 128 / 256):
@@ -252,7 +253,7 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     gs_bound = gs_max * 1.0001 if f32 else None
     # h1 is read at the rows R2 in place (row lists), no compacting copy; the ReLU / dropout
     # mask (h1 > 0 encodes ReLU and keep) is applied in the GEMM's store
-    fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
+    fast = f32 and _spmm.gemm_handwritten() and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
     h1c = None
     if need_w2:
         # (fp32 256 x 256 with bounds, or bf16 128 x 128: rows of h1 read in place through the list)
@@ -297,8 +298,8 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
             # grad_W1 = (Â·X)[R2]ᵀ · grad_pre1[R2]: a forward product restricted to rows R2
             z = spmm_csr(graph, x, tag="bwd_l1", c_select=rs.hint2[0],
                          out=_maybe_poisoned((n, x.shape[1]), x.dtype, dev))
-            if f32 and _spmm._gemm_scheme == "h2" and x.shape[1] == 256 and gpre1.shape[1] == 256:
-                z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
+            if f32 and _spmm.gemm_handwritten() and x.shape[1] == 256 and gpre1.shape[1] == 256:
+                z_bound = graph.inf_norm() * ctx.x_bound * 1.0001 if ctx.x_bound is not None else None
                 grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, z_bound,
                                                  gpre_bound, n_list=rs.n2)
             if grad_w1 is None:
@@ -362,7 +363,7 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
     grad_sup2 = spmm_csr(graph_t, gp.contiguous(), tag="bwd_l2", c_absmax=gs_max)
     del gp
     gs_bound = gs_max * 1.0001 if f32 else None
-    fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
+    fast = f32 and _spmm.gemm_handwritten() and grad_sup2.shape[1] == 256 and h1.shape[1] == 256
     if need_w2:
         grad_w2 = _spmm.weight_grad_rows(h1, grad_sup2, None, None, ctx.h_bound, gs_bound) \
             if (fast or not f32) else None

@@ -409,6 +409,11 @@ class HaloExchange:
             pos = (nz - off[:-1].repeat_interleave(mine)).to(torch.int32)       # position in the request
             n_nz = int(nz.numel())
             if static_key is not None:
+                # (a re-declared row set bumps the version inside the key — drop the
+                #  structures of the older versions instead of keeping them for ever)
+                if isinstance(static_key, tuple):
+                    for k in [k for k in self._static if isinstance(k, tuple) and k[:1] == static_key[:1]]:
+                        del self._static[k]
                 self._static[static_key] = (M, cut, src_rows, pos, n_nz)
             self.n_count_exchanges += 1
         else:
@@ -444,8 +449,15 @@ class ShardedGraph:
     def __init__(self, bounds, rank, world, a_block, at_block, group=None, exchange="halo",
                  graph_factory=CSRGraph, spmm_fn=spmm_csr, bwd_fn=_grad_pre_and_bias,
                  sparse_grad_exchange=True, overlap=True, compress_hidden=False, **plan_kw):
-        if exchange not in ("halo", "allgather"):
-            raise RuntimeError("exchange must be 'halo' or 'allgather'")
+        if exchange not in ("halo", "allgather", "rccl-allgather"):
+            raise RuntimeError("exchange must be 'halo', 'allgather' or 'rccl-allgather'")
+        # "rccl-allgather" = the all-gather layout moved by the COLLECTIVE itself
+        # (dist.all_gather_into_tensor: RCCL's all-gather on "nccl" — the north star's literal
+        # "RCCL all-gather of activations"); "allgather" moves the same bytes as one grouped
+        # point-to-point round (a direct mesh exchange)
+        self._rccl_gather = exchange == "rccl-allgather"
+        if self._rccl_gather:
+            exchange = "allgather"
         # dense halo exchanges are pipelined by source block (own rows | halo rows), see product()
         self.overlap = bool(overlap) and exchange == "halo" and world > 1
         self._graph_factory, self._plan_kw = graph_factory, plan_kw
@@ -488,6 +500,11 @@ class ShardedGraph:
         self.setup_stats = None     # filled by the shard-local constructors (from_rmat)
         self.static_grad_rows = None    # see declare_grad_rows
         self._grad_rows_version = 0
+        # forward exchange of a halo-mode graph may be switched to an all-gather form (bench.py's
+        # pre-timed A/B, set_forward_exchange); the padded block is built on first use
+        self.fwd_exchange = "halo" if exchange == "halo" else ("rccl-allgather" if self._rccl_gather else "allgather")
+        self._A_pad = None
+        self._col_global_fwd = a_block[1] if exchange == "halo" else None
 
     @classmethod
     def from_global_csr(cls, rowptr, col, val, n, rank, world, device=None, group=None, **kw):
@@ -543,16 +560,46 @@ class ShardedGraph:
         return sg
 
     # ---------------------------------------------------------------- exchange step
-    def all_gather_rows(self, local):
+    def set_forward_exchange(self, mode):
+        """Halo-mode graphs only: how the FORWARD dense exchange of a hidden layer moves its rows —
+        "halo" (the constructor's: only the rows this rank's block references, pipelined by source
+        block), "allgather" (every row to every rank, one grouped point-to-point round) or
+        "rccl-allgather" (the same layout through RCCL's all-gather collective).  The backward
+        exchanges (row-sparse / static gradient halo) and the constant-input halo are unchanged.
+        Must be set identically on every rank; the padded block is built on first use."""
+        if mode not in ("halo", "allgather", "rccl-allgather"):
+            raise RuntimeError("forward exchange must be 'halo', 'allgather' or 'rccl-allgather'")
+        if self.exchange_mode != "halo":
+            raise RuntimeError("set_forward_exchange: the graph was built in all-gather mode")
+        if mode != "halo" and self._A_pad is None:
+            rp, val = self._raw[False]
+            self._A_pad = self._graph_factory(rp, remap_columns(self._col_global_fwd, self.bounds, self.max_rows),
+                                              val, (self.n_local, self.world * self.max_rows), **self._plan_kw)
+        self.fwd_exchange = mode
+
+    def all_gather_rows(self, local, rccl=None):
         """[n_local, F] on every rank -> padded [P*max_rows, F] (rows past n_local of each slot
-        are never referenced by the remapped column indices).  A DIRECT (mesh) all-gather: every
-        rank sends its block straight to each of the P-1 peers in one grouped point-to-point
-        round — xGMI is a full mesh of point-to-point links, so all 7 transfers run concurrently
-        at one block-time, where a ring all-gather makes 7 sequential hops over one link
-        (≈ 8.4 ms vs ≈ 58.6 ms for 1.28 GB blocks)."""
+        are never referenced by the remapped column indices).
+        Default: a DIRECT (mesh) all-gather — every rank sends its block straight to each of the
+        P-1 peers in one grouped point-to-point round: xGMI is a full mesh of point-to-point links,
+        so all 7 transfers run concurrently at one block-time, where a ring all-gather makes 7
+        sequential hops over one link (≈ 8.4 ms vs ≈ 58.6 ms for 1.28 GB blocks).
+        `rccl=True` ("rccl-allgather"): ONE call of the collective, dist.all_gather_into_tensor
+        (RCCL's all-gather on the "nccl" backend), every rank contributing its padded max_rows
+        slot of the same buffer; which of the two is faster on a given node is what bench.py's
+        pre-timed A/B measures."""
+        rccl = self._rccl_gather if rccl is None else rccl
         F = local.shape[1]
         out = torch.empty((self.world * self.max_rows, F), dtype=local.dtype, device=local.device)
-        out[self.rank * self.max_rows:self.rank * self.max_rows + self.n_local].copy_(local)
+        slot = out[self.rank * self.max_rows:(self.rank + 1) * self.max_rows]
+        slot[:self.n_local].copy_(local)
+        if self.world > 1 and rccl:
+            # (the slot's tail past n_local travels too — never read by anybody; on RCCL the input
+            #  may alias its own slot of the output: the in-place form of the collective.  gloo — the
+            #  CPU rehearsals — gets a separate input.)
+            src = slot if local.is_cuda and dist.get_backend(self.group) == "nccl" else slot.clone()
+            dist.all_gather_into_tensor(out, src, group=self.group)
+            return out
         if self.world > 1:
             src = local if local.is_contiguous() else local.contiguous()
             sends, recvs = [], []
@@ -670,7 +717,14 @@ class ShardedGraph:
             kw["log_softmax"] = True
         tag = "bwd_local" if transpose else "fwd_local"
         which = "bwd" if transpose else "fwd"
-        if self.exchange_mode == "halo":
+        gather_fwd = (self.exchange_mode == "halo" and not transpose and row_nonzero is None
+                      and self.fwd_exchange != "halo")
+        if gather_fwd:        # (halo-mode graph whose forward exchange was switched to an all-gather)
+            gathered = self.all_gather_rows(local, rccl=self.fwd_exchange == "rccl-allgather")
+            self.last_recv_bytes[which] = ((self.n_global - self.n_local) * local.shape[1]
+                                           * local.element_size())
+            out = self._spmm(self._A_pad, gathered, bias=bias, relu=relu, tag=tag, **kw)
+        elif self.exchange_mode == "halo":
             h = self.halo_t if transpose else self.halo
             if row_nonzero is None and self.overlap:
                 a_own, a_halo = self.split_block(transpose)
@@ -717,12 +771,20 @@ class ShardedGraph:
             kw["log_softmax"] = True
         a_own, a_halo = self.split_block(False)
         state = h.exchange_compressed_begin(h_local.detach())
+        h_halo = None
+        if not self.overlap:                  # (--no-overlap is an A/B switch here too)
+            h_halo = h.exchange_compressed_end(state, h_local)
         sup_own = gemm(h_local, weight, h_bound)
         part = self._spmm(a_own, sup_own, tag="fwd_local")            # overlaps the transfers
         ev_w = self._tic(h_local)
-        h_halo = h.exchange_compressed_end(state, h_local)
+        if h_halo is None:
+            h_halo = h.exchange_compressed_end(state, h_local)
         self._toc(ev_w, "fwd_wait")
-        sup_halo = gemm(h_halo, weight, h_bound) if h_halo.shape[0] else \
+        # (the halo rows come from OTHER ranks — this rank's bound of max|h| does not
+        #  cover them, and the scaled fp16 scheme overflows silently above 2-4x its bound.  No bound:
+        #  gemm_xw256 takes one absmax pass over the small halo block under "h2"; the default
+        #  three-part bf16 scheme needs none.)
+        sup_halo = gemm(h_halo, weight, None) if h_halo.shape[0] else \
             h_halo.new_empty((0, weight.shape[1]))
         out = self._spmm(a_halo, sup_halo, bias=bias, relu=relu, tag="fwd_local", B2=part, **kw)
         self.last_recv_bytes["fwd"] = h.last_recv_bytes
@@ -737,6 +799,18 @@ class ShardedGraph:
     def __repr__(self):
         return (f"ShardedGraph(rank {self.rank}/{self.world}, rows [{self.r0},{self.r1}) of "
                 f"{self.n_global}, nnz_local {self.nnz_local}, exchange {self.exchange_mode})")
+
+
+def _check_static_rows(grad, flags):
+    """Opt-in debug check (PYGCN_CHECK_STATIC_ROWS=1; a host synchronisation): a gradient handed
+    to the STATIC row-sparse exchange must be zero outside the declared loss rows — a second loss on
+    other rows while the declaration stands would otherwise lose those rows silently."""
+    import os
+    if os.environ.get("PYGCN_CHECK_STATIC_ROWS") == "1":
+        stray = (grad != 0).any(1) & ~flags
+        if bool(stray.any()):
+            raise RuntimeError(f"static gradient rows: {int(stray.sum())} non-zero gradient rows lie outside "
+                               "the rows declared by declare_loss_rows / declare_grad_rows")
 
 
 class ShardedSpMMFunction(torch.autograd.Function):
@@ -779,6 +853,7 @@ class ShardedSpMMFunction(torch.autograd.Function):
                     # count exchange ran once, this step synchronises with nobody
                     flags = sg.static_grad_rows
                     static_key = ("loss rows", sg._grad_rows_version)
+                    _check_static_rows(grad_out, flags)
                 else:
                     # gradients of a loss on few labelled vertices: most rows are zero and need not
                     # travel.  The fused backward pass already produced the row bitmap; without it
@@ -836,6 +911,7 @@ class ShardedHiddenLayerFunction(torch.autograd.Function):
             if sg.sparse_grad_exchange:
                 if ctx.last_layer and sg.static_grad_rows is not None:
                     flags, static_key = sg.static_grad_rows, ("loss rows", sg._grad_rows_version)
+                    _check_static_rows(grad_pre, flags)
                 else:
                     flags = unpack_row_flags(hint[0], grad_pre.shape[0]) if hint is not None else \
                         (grad_pre != 0).any(1)

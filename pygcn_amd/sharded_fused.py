@@ -181,7 +181,7 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
             gs_bound = gs_max * 1.0001 if gs_max is not None else (
                 torch.linalg.vector_norm(grad_sup2, ord=float("inf")).float().reshape(1) * 1.0001
                 if rs.n2 else grad_sup2.new_zeros(1).float())
-        fast = f32 and _spmm._gemm_scheme == "h2" and grad_sup2.shape[1] == 256 and h1.shape[1] == 256 \
+        fast = f32 and _spmm.gemm_handwritten() and grad_sup2.shape[1] == 256 and h1.shape[1] == 256 \
             and rs.n2 > 0
         grad_w1 = grad_w2 = grad_b1 = None
         h1c = None

@@ -467,7 +467,10 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
 
-    Default scheme "h2": C-ABI gcn_gemm_xw256_f32_h2 — power-of-two scaling + two fp16 parts,
+    Default scheme "bf16x3": C-ABI gcn_gemm_xw256_f32_b3 — three bf16 parts per operand, six MFMAs
+    per product: a 24-bit significand, the fp32-equivalent of the reference's `torch.mm`; no scaling,
+    `x_bound` is ignored.  Scheme "h2" (set_gemm_scheme; 22-bit significand, half the matrix work):
+    C-ABI gcn_gemm_xw256_f32_h2 — power-of-two scaling + two fp16 parts,
     three MFMAs per product.  `x_bound` (DEVICE float tensor [1]) is any upper bound of max|X|; if
     the caller has none, max|X| is computed here by one reduction pass.  `y_absmax` (DEVICE float
     tensor [1], zeroed by the caller) receives max|Y|, from which a layer derives the next bound
@@ -479,20 +482,19 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     `bias` / `relu` / `dropout_p` / `seed`: FORWARD epilogue in the store, y = dropout(relu(acc +
     bias)) with the same Philox keep function as the SpMM epilogue — for a layer evaluated as
     (Â·X)·W + b, whose last stage is the GEMM (None if it cannot be fused).
-    Scheme "bf16x3" (set_gemm_scheme): C-ABI gcn_gemm_xw256_f32 — three bf16 parts, six MFMAs per
-    product, no scaling; full accuracy for 1e-30 <= |x| <= 3e38 (below that its low-order parts
-    underflow — tests/test_gemm_gpu.py)."""
+    Both schemes carry every option; "bf16x3" keeps full accuracy for 1e-30 <= |x| <= 3e38 (below
+    that its low-order parts underflow — tests/test_gemm_gpu.py)."""
     if (_gemm_scheme == "exact" or X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda
             or X.dim() != 2 or tuple(W.shape) != (256, 256) or X.shape[1] != 256 or X.shape[0] == 0
             or X.stride(1) != 1 or X.stride(0) % 4 or X.data_ptr() % 16 or W.stride(1) != 1):
         return None
     L = _native.lib()
     has_fwd_ep = bias is not None or relu or dropout_p > 0.0
-    if has_fwd_ep and (_gemm_scheme != "h2" or mask_src is not None
+    if has_fwd_ep and (mask_src is not None
                        or (bias is not None and (bias.dtype != torch.float32 or bias.numel() != 256
                                                  or not bias.is_contiguous() or bias.data_ptr() % 16))):
         return None
-    if mask_src is not None and (_gemm_scheme != "h2" or mask_src.dtype != torch.float32
+    if mask_src is not None and (mask_src.dtype != torch.float32
                                  or mask_src.dim() != 2 or mask_src.shape[1] != 256
                                  or mask_src.stride(1) != 1 or mask_src.stride(0) % 4
                                  or mask_src.data_ptr() % 16 or mask_src.device != X.device):
@@ -502,9 +504,7 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                                   or mask_rows.numel() < (rows.numel() if rows is not None else X.shape[0])):
         raise RuntimeError("gemm_xw256: mask_rows must be a contiguous int32 device list, one entry per output row")
     if rows is not None:
-        if _gemm_scheme != "h2":
-            X, rows = X.index_select(0, rows.long()), None
-        elif rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != X.device:
+        if rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != X.device:
             raise RuntimeError("gemm_xw256: rows must be a contiguous int32 device tensor")
     m_out = rows.numel() if rows is not None else X.shape[0]
     Y = torch.empty((m_out, 256), dtype=torch.float32, device=X.device)
@@ -517,23 +517,23 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
         x_bound = torch.linalg.vector_norm(X.detach(), ord=float("inf")).reshape(1)
     with torch.cuda.device(X.device):
         stream = torch.cuda.current_stream().cuda_stream
-        if x_bound is not None and _gemm_scheme == "h2":
+        ep = None
+        if has_fwd_ep or mask_src is not None:
+            seed_dev = None
+            if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
+                seed_dev, seed = seed.data_ptr(), 0
+            ep = _native.GcnGemmEpilogue(
+                bias.detach().data_ptr() if bias is not None else None, int(bool(relu)),
+                float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
+                mask_src.data_ptr() if mask_src is not None else None,
+                mask_src.stride(0) if mask_src is not None else 0, float(mask_scale),
+                mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None,
+                int(row_base))
+        if _gemm_scheme == "h2":
             if x_bound.dtype != torch.float32 or x_bound.numel() != 1 or x_bound.device != X.device:
                 raise RuntimeError("gemm_xw256: x_bound must be one float32 on the operand's device")
             ws_bytes = L.gcn_gemm_xw256_h2_workspace_bytes()
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
-            ep = None
-            if has_fwd_ep or mask_src is not None:
-                seed_dev = None
-                if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
-                    seed_dev, seed = seed.data_ptr(), 0
-                ep = _native.GcnGemmEpilogue(
-                    bias.detach().data_ptr() if bias is not None else None, int(bool(relu)),
-                    float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
-                    mask_src.data_ptr() if mask_src is not None else None,
-                    mask_src.stride(0) if mask_src is not None else 0, float(mask_scale),
-                    mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None,
-                    int(row_base))
             rc = L.gcn_gemm_xw256_f32_h2(X.data_ptr(), X.stride(0),
                                          rows.data_ptr() if rows is not None else None,
                                          W.data_ptr(), W.stride(0),
@@ -545,13 +545,14 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
                 raise RuntimeError("gemm_xw256: non-finite output — x_bound was smaller than max|X| (the "
                                    "fp16 parts overflowed) or the operands hold inf / NaN")
             return Y
-        ws_bytes = L.gcn_gemm_xw256_workspace_bytes()
+        ws_bytes = L.gcn_gemm_xw256_b3_workspace_bytes()
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
-        rc = L.gcn_gemm_xw256_f32(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), Y.data_ptr(),
-                                  Y.stride(0), X.shape[0], ws.data_ptr(), ws_bytes, stream)
-    _native.check(rc, "gcn_gemm_xw256_f32")
-    if y_absmax is not None:
-        y_absmax.copy_(Y.abs().max())
+        rc = L.gcn_gemm_xw256_f32_b3(X.data_ptr(), X.stride(0),
+                                     rows.data_ptr() if rows is not None else None,
+                                     W.data_ptr(), W.stride(0), Y.data_ptr(), Y.stride(0), m_out,
+                                     y_absmax.data_ptr() if y_absmax is not None else None,
+                                     ep, ws.data_ptr(), ws_bytes, stream)
+    _native.check(rc, "gcn_gemm_xw256_f32_b3")
     return Y
 
 
@@ -613,7 +614,7 @@ def layer_gemm_reassociable(x, weight, bias):
     if x.dim() != 2 or not x.is_cuda or x.stride(1) != 1 or weight.dim() != 2 or x.dtype != weight.dtype:
         return False
     if x.dtype == torch.float32:
-        return (_gemm_scheme == "h2" and tuple(weight.shape) == (256, 256) and x.shape[1] == 256
+        return (_gemm_scheme != "exact" and tuple(weight.shape) == (256, 256) and x.shape[1] == 256
                 and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())))
     if x.dtype == torch.bfloat16:
         return (tuple(weight.shape) in ((128, 128), (128, 256)) and x.shape[1] == weight.shape[0]
@@ -661,7 +662,8 @@ def _identity_list(n, device):
 def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None):
     """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] through the gather-fused MFMA kernels: the weight gradient
     `inputᵀ · grad_support` over a LIST of rows, without compacting either operand first.
-    fp32 [*, 256] x [*, 256] (C-ABI gcn_gemm_atg256_f32, scaled two-part fp16 scheme) or bf16
+    fp32 [*, 256] x [*, 256] (C-ABI gcn_gemm_atg256_f32_b3: three bf16 parts, fp32-equivalent — or
+    gcn_gemm_atg256_f32, the scaled two-part fp16 scheme, under set_gemm_scheme("h2")) or bf16
     storage [*, 128] x [*, 128] (C-ABI gcn_gemm_atg_bf16: fp32 accumulation, result rounded once
     to bf16).  rows_*: int32 device index lists or None (= all rows, in order).  A list may be
     longer than `n_list` (padding to a multiple of 16, padded_row_list()); unpadded lists are
@@ -674,7 +676,7 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
                 or A.stride(0) % 2 or G.stride(0) % 2 or A.data_ptr() % 4 or G.data_ptr() % 4
                 or _native.lib().gcn_gemm_atg_bf16_workspace_bytes(16, A.shape[1], G.shape[1]) == 0):
             return None
-    elif (_gemm_scheme != "h2" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
+    elif (_gemm_scheme == "exact" or A.dtype != torch.float32 or G.dtype != torch.float32 or not A.is_cuda
             or A.dim() != 2 or G.dim() != 2 or A.shape[1] != 256 or G.shape[1] != 256 or A.stride(1) != 1
             or G.stride(1) != 1 or A.stride(0) % 4 or G.stride(0) % 4 or A.data_ptr() % 16 or G.data_ptr() % 16):
         return None
@@ -710,6 +712,17 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
                                      torch.cuda.current_stream().cuda_stream)
         _native.check(rc, "gcn_gemm_atg_bf16")
         return out.to(torch.bfloat16)
+    out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
+    ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_list)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+    if _gemm_scheme != "h2":            # three bf16 parts: no bounds
+        with torch.cuda.device(A.device):
+            rc = L.gcn_gemm_atg256_f32_b3(A.data_ptr(), A.stride(0), lists[0].data_ptr(),
+                                          G.data_ptr(), G.stride(0), lists[1].data_ptr(), n_list,
+                                          out.data_ptr(), out.stride(0), ws.data_ptr(), ws_bytes,
+                                          torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "gcn_gemm_atg256_f32_b3")
+        return out
     # (no bound supplied: a reduction pass — over the LISTED rows only, the others may hold anything)
     if a_bound is None:
         src = A.detach()[:n_list] if rows_a is None else A.detach().index_select(0, rows_a[:n_list].long())
@@ -717,9 +730,6 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     if g_bound is None:
         src = G.detach()[:n_list] if rows_g is None else G.detach().index_select(0, rows_g[:n_list].long())
         g_bound = torch.linalg.vector_norm(src, ord=float("inf")).reshape(1)
-    out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
-    ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_list)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     with torch.cuda.device(A.device):
         rc = L.gcn_gemm_atg256_f32(A.data_ptr(), A.stride(0), lists[0].data_ptr(),
                                    G.data_ptr(), G.stride(0), lists[1].data_ptr(), n_list,
@@ -729,8 +739,23 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     return out
 
 
-_gemm_scheme = "h2"
+_gemm_scheme = "bf16x3"
 _bound_check = False
+
+
+def gemm_scheme():
+    """The current scheme of the fp32 256 -> 256 GEMMs (set_gemm_scheme)."""
+    return _gemm_scheme
+
+
+def gemm_handwritten():
+    """Are the 256-wide fp32 GEMMs on the hand-written MFMA kernels (either decomposition)?"""
+    return _gemm_scheme != "exact"
+
+
+def gemm_needs_bounds():
+    """Only the scaled two-part fp16 scheme needs an upper bound of max|operand|."""
+    return _gemm_scheme == "h2"
 
 
 def set_bound_check(enabled):
@@ -746,10 +771,12 @@ def set_bound_check(enabled):
 
 def set_gemm_scheme(name):
     """How the fp32 256 -> 256 GEMMs of the layers are evaluated:
-    "h2" (default): the scaled two-part fp16 MFMA kernels (22-bit significand, 4e-7 normwise vs fp64)
-        wherever a bound of max|X| is known — forward, grad_input, gather-fused weight gradients;
-    "bf16x3": the three-part bf16 kernel for the forward / grad_input GEMMs (no assumption about
-        the data's dynamic range), hipBLASLt for the weight gradients;
+    "bf16x3" (default since round 4): three bf16 parts per operand, six MFMAs per product — a 24-bit
+        significand, the fp32-EQUIVALENT of the reference's `torch.mm` (pygcn/layers.py:33); no
+        scaling, no bounds, fp32's range; forward (with the layer epilogue), grad_input (with the
+        mask) and the gather-fused weight gradients;
+    "h2": the scaled two-part fp16 MFMA kernels (22-bit significand, half the matrix work, 4e-7
+        normwise vs fp64 on well-scaled data) wherever a bound of max|X| is known — opt-in;
     "exact": no hand-written fp32 GEMM at all — every dense product is `torch.mm` (hipBLASLt's exact
         fp32 MFMA path, the arithmetic of the reference's `torch.mm(input, self.weight)`,
         pygcn/layers.py:33) and the layers keep the reference's order Â·(X·W).  The SpMM kernels
@@ -818,11 +845,12 @@ def _dense_forward(input, weight, x_bound=None, y_absmax=None):
 
 
 def _weight_grad(input, grad, a_bound=None, g_bound=None):
-    """inputᵀ · grad: the hand-written MFMA kernel for 256-wide fp32 layers when the caller knows
-    bounds of both operands' maxima (the kernel's scaling needs them; two reduction passes over
-    [N, 256] tensors would cost what the kernel saves), otherwise hipBLASLt with the reduction
-    over the graph's vertices cut into K_SPLIT slabs."""
-    if (a_bound is not None and g_bound is not None and _gemm_scheme == "h2") or \
+    """inputᵀ · grad: the hand-written MFMA kernel for 256-wide fp32 layers — always under the
+    three-part bf16 scheme; under "h2" when the caller knows bounds of both operands' maxima (the
+    scaling needs them; two reduction passes over [N, 256] tensors would cost what the kernel saves)
+    — otherwise hipBLASLt with the reduction over the graph's vertices cut into K_SPLIT slabs."""
+    if (_gemm_scheme == "bf16x3" and input.dtype == torch.float32) or \
+            (a_bound is not None and g_bound is not None and _gemm_scheme == "h2") or \
             (input.dtype == torch.bfloat16 and grad.dtype == torch.bfloat16 and input.is_cuda):
         out = weight_grad_rows(input, grad, a_bound=a_bound, g_bound=g_bound)
         if out is not None:
@@ -861,7 +889,7 @@ def _dense_grads(input, weight, grad, need_in, need_w, rows=None):
         y_max = torch.zeros(1, dtype=torch.float32, device=grad.device) \
             if (grad.is_cuda and grad.dtype == torch.float32) else None
         grad_in = gemm_xw256(grad, weight.t().contiguous(), None, y_max)
-        if grad_in is not None and y_max is not None and _gemm_scheme == "h2":
+        if grad_in is not None and y_max is not None and _gemm_scheme != "exact":
             remember_absmax(grad_in, y_max)      # (the layer below bounds its masked gradient by it)
         if grad_in is None:
             grad_in = gemm_bf16(grad, weight.t().contiguous())
@@ -953,10 +981,12 @@ class GraphConvFunction(torch.autograd.Function):
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         # (a layer input that needs no gradient is the constant feature matrix: its maximum is
         #  computed once and reused as the scaled GEMM's bound)
-        x_bound = absmax_cached(input) if (input.dtype == torch.float32 and not input.requires_grad
+        # (bounds exist for the scaled fp16 scheme alone: the default three-part bf16 GEMMs need none)
+        bounds = gemm_needs_bounds()
+        x_bound = absmax_cached(input) if (bounds and input.dtype == torch.float32 and not input.requires_grad
                                            and input.is_cuda) else None
         const_input = not input.requires_grad and input.is_cuda
-        if x_bound is None and input.dtype == torch.float32 and input.is_cuda:
+        if bounds and x_bound is None and input.dtype == torch.float32 and input.is_cuda:
             x_bound = known_absmax(input)       # (left by the layer that produced this tensor)
         # REASSOCIATED for a constant input on the shape the GEMM kernel carries the epilogue for
         # (256 -> 256 fp32): out = epilogue((A·input)·W + b).  Same two kernels and bytes in
@@ -1030,8 +1060,8 @@ class GraphConvFunction(torch.autograd.Function):
             grad_w = grad_in = None
             if need_w:
                 grad_w = weight_grad_rows(input, grad_sup, rs.rows2_padded, None, ctx.x_bound, gs_bound,
-                                          n_list=rs.n2) if (f32 and ctx.x_bound is not None
-                                                            and _gemm_scheme == "h2") else None
+                                          n_list=rs.n2) if (f32 and _gemm_scheme != "exact" and
+                                                            (ctx.x_bound is not None or not gemm_needs_bounds())) else None
                 if grad_w is None:
                     grad_w = _weight_grad(input.index_select(0, rs.rows2), grad_sup)
             if need_in:
@@ -1062,7 +1092,7 @@ class GraphConvFunction(torch.autograd.Function):
             grad_w = None
             if need_w:
                 grad_w = weight_grad_rows(input, g, meta["padded"], None, ctx.z_bound, bound,
-                                          n_list=rows.numel()) if (f32 and ctx.z_bound is not None) else None
+                                          n_list=rows.numel()) if (f32 and (ctx.z_bound is not None or not gemm_needs_bounds())) else None
                 if grad_w is None:
                     grad_w = _weight_grad(input.index_select(0, rows), g)
             return None, grad_w, grad_bias, None, None, None, None, None

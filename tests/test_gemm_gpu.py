@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import inputs as gin
-from conftest import assert_normwise
+from conftest import assert_normwise, assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -17,19 +17,50 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def h2_scheme():
+    """The scaled two-part fp16 scheme (the one that HAS a bound), restored afterwards."""
+    from pygcn_amd import spmm as S
+    before = S.gemm_scheme()
+    S.set_gemm_scheme("h2")
+    yield
+    S.set_gemm_scheme(before)
+
+
 def _run(scheme, X, W, bound=None):
     """Y through one of the two kernels; for "h2" the bound defaults to the exact max|X|."""
     from pygcn_amd import spmm as S
     from pygcn_amd.spmm import gemm_xw256
-    if scheme == "bf16x3":
-        S.set_gemm_scheme("bf16x3")
-        try:
+    before = S.gemm_scheme()
+    S.set_gemm_scheme(scheme)
+    try:
+        if scheme == "bf16x3":
             return gemm_xw256(X, W)
-        finally:
-            S.set_gemm_scheme("h2")
-    finite = torch.where(torch.isfinite(X), X.abs(), torch.zeros_like(X))
-    b = (finite.max() if bound is None else torch.as_tensor(bound, device=X.device)).float().reshape(1)
-    return gemm_xw256(X, W, x_bound=b)
+        finite = torch.where(torch.isfinite(X), X.abs(), torch.zeros_like(X))
+        b = (finite.max() if bound is None else torch.as_tensor(bound, device=X.device)).float().reshape(1)
+        return gemm_xw256(X, W, x_bound=b)
+    finally:
+        S.set_gemm_scheme(before)
+
+
+@pytest.mark.parametrize("M", [1, 257, 4099, 600_001])
+def test_three_part_pipeline_equals_the_round_one_kernel_bitwise(dev, M):
+    """gcn_gemm_xw256_f32_b3 (round 4: the fp32-equivalent scheme in the DMA / persistent pipeline)
+    issues the six MFMAs of a product in the order of round 1's gcn_gemm_xw256_f32: same bits, at
+    heights that give a persistent workgroup one ragged tile, several tiles, and a cross-tile
+    prefetch."""
+    from pygcn_amd import _native
+    L = _native.lib()
+    g = torch.Generator(device=dev).manual_seed(M)
+    X = torch.randn(M, 256, generator=g, device=dev) * (10 ** (4 * torch.rand(M, 1, generator=g, device=dev) - 2))
+    W = torch.randn(256, 256, generator=g, device=dev)
+    old = torch.empty(M, 256, device=dev)
+    ws = torch.empty(L.gcn_gemm_xw256_workspace_bytes(), dtype=torch.uint8, device=dev)
+    _native.check(L.gcn_gemm_xw256_f32(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), old.data_ptr(),
+                                       old.stride(0), M, ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream), "gcn_gemm_xw256_f32")
+    new = _run("bf16x3", X, W)
+    assert torch.equal(new, old)
 
 
 @pytest.mark.parametrize("scheme", ["bf16x3", "h2"])
@@ -123,7 +154,7 @@ def test_gemm_precision_at_the_edges_of_fp32(dev, scheme):
         assert float(small_rows.max()) <= 2e-3          # ~11 bits left on those rows (documented)
 
 
-def test_gemm_output_maximum_side_channel(dev):
+def test_gemm_output_maximum_side_channel(dev, gemm_scheme):
     """gcn_gemm_xw256_f32_h2 reports max|Y| (the next layer's bound) without a pass over Y; and
     without a caller-supplied bound the wrapper computes max|X| itself."""
     from pygcn_amd.spmm import gemm_xw256
@@ -144,7 +175,7 @@ def test_gemm_declines_other_shapes(dev):
     assert gemm_xw256(odd, torch.randn(256, 256, device=dev)) is None
 
 
-def test_layer_256_to_256_through_custom_gemm(oracle, dev):
+def test_layer_256_to_256_through_custom_gemm(oracle, dev, gemm_scheme):
     """The C3/C4 layer shape: forward and backward of GraphConvolution(256, 256) run the custom
     GEMM (forward and grad_input) and must still match the oracle at the north-star tolerance."""
     from pygcn_amd import CSRGraph, GraphConvolution
@@ -163,14 +194,15 @@ def test_layer_256_to_256_through_custom_gemm(oracle, dev):
     w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
     y_ref, _ = oracle.gc_forward(x, w, b, a)
     gx, gw, gb, _ = oracle.gc_backward(x, w, True, a, go)
+    _, gw64, gb64 = oracle.gc_backward_f64(x, w, True, a, go, need_grad_x=False)
     assert_normwise(y.detach().cpu(), y_ref, 1e-5, "y")
     assert_normwise(xg.grad.cpu(), gx, 1e-5, "grad_x")
-    assert_normwise(layer.weight.grad.cpu(), gw, 2e-5, "grad_w")
-    assert_normwise(layer.bias.grad.cpu(), gb, 2e-5, "grad_b")
+    assert_parity(layer.weight.grad.cpu(), gw, gw64, "grad_w")      # (20 000-term float32 reductions)
+    assert_parity(layer.bias.grad.cpu(), gb, gb64, "grad_b")
 
 
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 100, 4097, 70001])
-def test_weight_gradient_over_row_lists_matches_fp64(dev, M):
+def test_weight_gradient_over_row_lists_matches_fp64(dev, M, gemm_scheme):
     """gcn_gemm_atg256_f32: Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] with and without row lists (the weight
     gradient of pygcn/layers.py:33 over the rows on which the gradient can be non-zero)."""
     from pygcn_amd.spmm import weight_grad_rows
@@ -211,7 +243,7 @@ def test_weight_gradient_degenerate_lists(dev):
     assert weight_grad_rows(A[:, :128], G) is None
 
 
-def test_gemm_with_row_list(dev):
+def test_gemm_with_row_list(dev, gemm_scheme):
     """gcn_gemm_xw256_f32_h2 with x_rows: output row r = X[rows[r]] · W, unlisted rows never read."""
     from pygcn_amd.spmm import gemm_xw256
     X = torch.randn(5000, 256, device=dev)
@@ -249,7 +281,7 @@ def test_bf16_gemm_matches_fp32_on_rounded_inputs(dev, K, N, M):
     assert gemm_bf16(X[:, :64], W[:64]) is None and gemm_bf16(X.float(), W.float()) is None
 
 
-def test_gemm_with_fused_relu_dropout_mask(dev):
+def test_gemm_with_fused_relu_dropout_mask(dev, gemm_scheme):
     """mask_src: y = mask_src[input row] > 0 ? y * scale : 0 in the GEMM's own store (the backward
     of the fused ReLU / dropout epilogue on the grad_input GEMM), with and without a row list."""
     from pygcn_amd.spmm import gemm_xw256
@@ -269,7 +301,7 @@ def test_gemm_with_fused_relu_dropout_mask(dev):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.3, 0.5])
-def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p):
+def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p, gemm_scheme):
     """bias + ReLU + inverted dropout in the GEMM's store (a layer evaluated as (Â·X)·W + b): the
     same values — and the SAME Philox keep bits for a given (seed, row, column) — as the SpMM
     epilogue applied to the plain product (checked through an identity adjacency)."""
@@ -342,7 +374,7 @@ def test_bf16_gemm_forward_epilogue(dev, K, N, p):
     assert bool(((b_only.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5 * float(ref.abs().max())).all())
 
 
-def test_a_bound_that_is_too_small_is_never_silent(dev):
+def test_a_bound_that_is_too_small_is_never_silent(dev, h2_scheme):
     """the scaled fp16 GEMM trusts the caller's upper bound of max|X|.  A bound that is
     too small overflows the fp16 parts; that must surface — y_absmax becomes non-finite (its
     integer maximum keeps inf / NaN patterns), a consumer scaled by such a bound stores NaN, and
@@ -494,7 +526,7 @@ def test_bf16_gemm_mask_at_the_wider_shapes(dev, K, N):
     assert torch.equal(gemm_bf16(X, W, mask_src=H, mask_rows=perm, mask_scale=1.0), listed)
 
 
-def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev):
+def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev, gemm_scheme):
     """The fp32 GEMM moves X and W by asynchronous HBM -> LDS DMA with hand-counted waits
     (gcn_gemm.hip, GEMM_H2_XLDS): a wait that is one too weak would show as run-to-run noise.
     Many launches over inputs that give every persistent workgroup several tiles (cross-tile

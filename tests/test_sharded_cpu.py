@@ -62,7 +62,7 @@ def _cpu_bwd_with_hint(grad_out, out, relu, scale, want_bias):
 
 
 def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False, build="global",
-            overlap=True, static_rows=False, compress=False):
+            overlap=True, static_rows=False, compress=False, fwd_switch=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -102,7 +102,10 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
             del ref
         assert sg.overlap == (overlap and exchange == "halo" and world > 1)
         recv, full = sg.exchange_rows()
-        assert recv <= full and (exchange == "allgather") == (recv == full and sg.halo is None)
+        assert recv <= full and (exchange != "halo") == (recv == full and sg.halo is None)
+        assert sg._rccl_gather == (exchange == "rccl-allgather")
+        if fwd_switch is not None:       # a halo-mode graph whose FORWARD exchange is an all-gather
+            sg.set_forward_exchange(fwd_switch)
         assert sg.bounds[0] == 0 and sg.bounds[-1] == n and sg.n_local == sg.r1 - sg.r0
         x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, fin)).astype(np.float32))
         labels = torch.from_numpy(np.random.default_rng(2).integers(0, ncls, n))
@@ -144,6 +147,12 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
         # exchanged once; a second step exchanges nothing for layer 1; an in-place edit of the
         # features is noticed; an input that requires grad takes the general (exchanging) path and
         # gives the same parameter gradients
+        if fwd_switch is not None:
+            # the hidden layer's forward exchange moved EVERY remote row (the collective's volume),
+            # the backward exchange is still the row-sparse halo
+            assert sg.last_recv_bytes["fwd"] == (n - sg.n_local) * ncls * 4
+            sent, dense = sg.halo_t.last_sparse_rows
+            assert sent <= dense
         if exchange == "halo":
             # the layer-2 gradient rows travelled sparsely: only rows of the n/5 labelled vertices
             sent, dense = sg.halo_t.last_sparse_rows
@@ -183,7 +192,7 @@ def _worker(rank, world, port, n, n_edges, out_dir, exchange, bitmap_hint=False,
 
 
 @pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (8, "halo"), (2, "allgather"),
-                                            (3, "allgather")])
+                                            (3, "allgather"), (2, "rccl-allgather"), (3, "rccl-allgather")])
 def test_sharded_gcn_matches_unsharded_oracle(world, exchange, tmp_path, oracle):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -225,6 +234,18 @@ def test_declared_loss_rows_make_the_gradient_exchange_static(world, tmp_path, o
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, _free_port(), 4000, 30000, str(tmp_path), "halo", False, "global",
                             True, True), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+@pytest.mark.parametrize("world,mode", [(2, "rccl-allgather"), (3, "rccl-allgather"), (3, "allgather")])
+def test_forward_exchange_switched_to_the_collective(world, mode, tmp_path, oracle):
+    """ShardedGraph.set_forward_exchange: a halo-mode graph whose hidden-layer FORWARD exchange is
+    the all-gather — through dist.all_gather_into_tensor (the north star's literal "RCCL all-gather of
+    activations"; gloo here) or the grouped point-to-point round — while the constant-input halo
+    and the row-sparse backward exchange stay as they are: oracle parity in the worker."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), 4000, 30000, str(tmp_path), "halo", False, "global",
+                            True, False, False, mode), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
 
 

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import inputs as gin
-from conftest import assert_normwise, load_golden
+from conftest import assert_normwise, assert_parity, load_golden
 from make_golden_cases import EDGE_CASES
 
 pytestmark = pytest.mark.gpu
@@ -268,10 +268,11 @@ def test_rmat_graph_forward_backward_vs_oracle(oracle, dev):
     w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
     y_ref, _ = oracle.gc_forward(x, w, b, a)
     gx, gw, gb, _ = oracle.gc_backward(x, w, True, a, go)
+    _, gw64, gb64 = oracle.gc_backward_f64(x, w, True, a, go, need_grad_x=False)
     assert_normwise(y.detach().cpu(), y_ref, TOL, "y")
     assert_normwise(xg.grad.cpu(), gx, TOL, "grad_x")
-    assert_normwise(layer.weight.grad.cpu(), gw, 2e-5, "grad_w")   # 30k-term fp32 GEMM reduction
-    assert_normwise(layer.bias.grad.cpu(), gb, 2e-5, "grad_b")
+    assert_parity(layer.weight.grad.cpu(), gw, gw64, "grad_w")   # 30k-term fp32 reductions: float64 arbiter
+    assert_parity(layer.bias.grad.cpu(), gb, gb64, "grad_b")
 
 
 def test_errors_are_runtime_errors(dev):
@@ -313,6 +314,7 @@ def test_batched_samples_match_per_sample_loop(oracle, dev):
     w, b = layer.weight.detach().cpu().numpy(), layer.bias.detach().cpu().numpy()
     gw_ref = np.zeros_like(w)
     gb_ref = np.zeros_like(b)
+    gw64, gb64 = np.zeros(w.shape), np.zeros(b.shape)
     for i in range(k):
         yi, _ = oracle.gc_forward(x[i], w, b, a)
         gx, gw, gb, _ = oracle.gc_backward(x[i], w, True, a, go[i])
@@ -320,8 +322,11 @@ def test_batched_samples_match_per_sample_loop(oracle, dev):
         assert_normwise(xg.grad[i].cpu(), gx, TOL, f"grad_x[{i}]")
         gw_ref += gw
         gb_ref += gb
-    assert_normwise(layer.weight.grad.cpu(), gw_ref, 2e-5, "grad_w")
-    assert_normwise(layer.bias.grad.cpu(), gb_ref, 2e-5, "grad_b")
+        _, w64, b64 = oracle.gc_backward_f64(x[i], w, True, a, go[i], need_grad_x=False)
+        gw64 += w64
+        gb64 += b64
+    assert_parity(layer.weight.grad.cpu(), gw_ref, gw64, "grad_w")
+    assert_parity(layer.bias.grad.cpu(), gb_ref, gb64, "grad_b")
     # the loop itself on the GPU path gives the same numbers
     loop = torch.stack([layer(torch.from_numpy(x[i]).to(dev), g) for i in range(k)])
     assert_normwise(loop.detach().cpu(), y.detach().cpu().numpy(), TOL, "loop vs batched")
@@ -377,9 +382,10 @@ def test_fused_dropout_autograd_and_model(oracle, dev):
     np.testing.assert_allclose(yn[kept], (z / (1 - p))[kept], rtol=2e-5, atol=1e-6)
     g_pre = np.where(kept, go / np.float32(1 - p), 0).astype(np.float32)
     gx, gw, gb, _ = oracle.gc_backward(x, w, True, a, g_pre)
+    _, gw64, gb64 = oracle.gc_backward_f64(x, w, True, a, g_pre, need_grad_x=False)
     assert_normwise(xg.grad.cpu(), gx, TOL, "grad_x")
-    assert_normwise(layer.weight.grad.cpu(), gw, 2e-5, "grad_w")
-    assert_normwise(layer.bias.grad.cpu(), gb, 2e-5, "grad_b")
+    assert_parity(layer.weight.grad.cpu(), gw, gw64, "grad_w")
+    assert_parity(layer.bias.grad.cpu(), gb, gb64, "grad_b")
     # the standalone backward kernel, odd sizes / bf16 / aliasing-free
     for dt, nel in ((torch.float32, 1000003), (torch.bfloat16, 4096), (torch.bfloat16, 77)):
         go_t = torch.randn(nel, device=dev).to(dt)
@@ -842,7 +848,7 @@ def test_model_uses_fused_log_softmax_and_matches_torch(oracle, dev):
         torch.nn.functional.nll_loss(ref_out[idx], lab).backward()
         assert_normwise(out.detach().cpu(), ref_out.detach().cpu().numpy(), TOL, "fused output")
         for a_, p in zip(got, model.parameters()):
-            assert_normwise(a_.cpu(), p.grad.cpu().numpy(), 2e-5, "fused gradients")
+            assert_normwise(a_.cpu(), p.grad.cpu().numpy(), TOL, "fused gradients")
 
 
 def test_dropout_under_hipgraph_replay_draws_fresh_masks(oracle, dev):
@@ -1007,13 +1013,13 @@ def test_layer_output_carries_its_maximum_to_the_next_layer(dev):
 
 
 @pytest.mark.parametrize("width,how", [(256, "reassociated"), (128, "row-selected")])
-def test_first_layer_weight_gradient_without_a_transpose_product(oracle, dev, width, how):
+def test_first_layer_weight_gradient_without_a_transpose_product(oracle, dev, width, how, gemm_scheme):
     """A first layer (its input needs no gradient) under a row-sparse grad_pre forms
     grad_W = (A·X)ᵀ·grad_pre: at 256 -> 256 fp32 the layer is evaluated as (A·X)·W and keeps A·X
     from its forward pass (no sparse product in backward at all); other widths run a forward
     product restricted to the rows grad_pre is non-zero on.  Same gradients as the
-    transpose-product path (taken with row compaction off and the three-part GEMM scheme, which
-    switches the reassociation off)."""
+    transpose-product path (taken with row compaction off and the "exact" GEMM scheme — hipBLASLt,
+    the reference's order Â·(X·W) — which switches the reassociation off)."""
     import importlib
     from pygcn_amd import CSRGraph, GraphConvolution
     from pygcn_amd.utils import rmat_graph
@@ -1044,17 +1050,17 @@ def test_first_layer_weight_gradient_without_a_transpose_product(oracle, dev, wi
                 S.spmm_csr = orig
             return [p.grad.clone() for p in layer.parameters()], seen
         finally:
-            S.set_row_compaction(True)
-            S.set_gemm_scheme("h2")
+            S.set_row_compaction(False)
+            S.set_gemm_scheme(gemm_scheme)
             S._poison_unwritten = False
 
-    new, seen = grads(True, "h2")
-    ref, seen_ref = grads(False, "bf16x3")
+    new, seen = grads(True, gemm_scheme)
+    ref, seen_ref = grads(False, "exact")
     backward = [sel for tag, sel in seen if tag == "bwd"]
     assert backward == ([] if how == "reassociated" else [True]), seen
     assert [sel for tag, sel in seen_ref if tag == "bwd"] == [False], seen_ref
     for a_, b_ in zip(new, ref):
-        assert_normwise(a_.cpu(), b_.cpu().numpy(), 2e-5, how + " grad")
+        assert_normwise(a_.cpu(), b_.cpu().numpy(), 2e-5, how + " grad")     # (two float32 routes, each within 1e-5 of exact)
 
 
 @pytest.mark.parametrize("F,dtype", [(256, torch.float32), (64, torch.float32), (128, torch.bfloat16)])
