@@ -164,10 +164,12 @@ int gcn_spmm_csr(const gcn_csr_plan *plan, int dtype, const void *B, int64_t ldb
  * Epilogue applied to every output row inside the kernel's store, in this order:
  *   x = acc + bias[f]            (bias may be NULL)          — pygcn/layers.py:35-36
  *   x = max(x, 0)                if relu                     — F.relu,   pygcn/models.py:48 (upstream)
- *   x = keep ? x / (1 - p) : 0   if dropout_p > 0            — F.dropout, pygcn/models.py:50 (upstream)
+ *   x = keep ? x * s : 0         if dropout_p > 0            — F.dropout, pygcn/models.py:50 (upstream)
  * The keep bit of element (row, f) is a pure function of (seed, drop_row_base + row, f), identical
  * for every kernel variant.  T = clamp(round(p * 65536), 1, 65535) (p is honoured to 2^-17; p = 1/2
- * exactly), w = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi)), and
+ * exactly); s = 65536 / (65536 - T) = 1 / (keep probability of that T) (ABI 24; before: 1 / (1 - p) of
+ * the unquantised p), so E[dropout(x)] = x exactly — the backward scale of a caller must be the
+ * same number (pygcn_amd.spmm.dropout_scale); w = Philox4x32-10(counter = (row_lo, row_hi, block, 0), key = (seed_lo, seed_hi)), and
  *   T != 32768 (ABI 22: eight 16-bit fields per call):
  *     block = ((f >> 4) << 1) | ((f >> 2) & 1),   field = (((f >> 3) & 1) << 2) | (f & 3)
  *     keep  = ((w[field >> 1] >> 16 * (field & 1)) & 0xFFFF) >= T

@@ -336,6 +336,16 @@ def train_trajectory(x, adj, params, labels, idx_train, epochs, lr=0.01, weight_
 
 
 # ---------------------------------------------------------------- fused dropout (test checker)
+def dropout_scale(p):
+    """Scale of the kept elements: 1 / (keep probability of the QUANTISED threshold dropout_keep
+    uses) = 65536 / (65536 - thresh), as float32 — 1 / (1 - p) at p = 1/2, within 2^-17 elsewhere
+    (include/gcn_spmm.h, struct gcn_epilogue; upstream's F.dropout scales by 1 / (1 - p),
+    pygcn/models.py:50)."""
+    t = int(np.float64(np.float32(p)) * 65536.0 + 0.5)
+    thresh = min(65535, max(1, t))
+    return np.float32(65536.0) / np.float32(65536 - thresh)
+
+
 def dropout_keep(seed, rows, F, p, row_base=0):
     """numpy restatement of the kernels' dropout keep function (include/gcn_spmm.h, struct
     gcn_epilogue, ABI 23) — the stand-in for the mask `F.dropout` draws in the reference model

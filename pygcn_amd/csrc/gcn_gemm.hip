@@ -59,6 +59,11 @@ static inline uint32_t gcn_dropout_threshold16(float p)
     const double t = (double)p * 65536.0 + 0.5;
     return (uint32_t)std::min(65535.0, std::max(1.0, (double)(int64_t)t));
 }
+// (the scale of the QUANTISED keep probability, as in gcn_spmm.hip: E[dropout(x)] = x exactly)
+static inline float gcn_dropout_scale16(uint32_t thresh)
+{
+    return thresh == 0u ? 1.f : 65536.f / (float)(65536u - thresh);
+}
 
 namespace {
 
@@ -423,7 +428,7 @@ struct H2Epi {
     const float *bias;          // [256] or NULL
     int relu;
     uint32_t drop_thresh;       // keep an element iff its 16-bit field >= drop_thresh (0: none)
-    float drop_scale;           // 1 / (1 - p)
+    float drop_scale;           // 65536 / (65536 - drop_thresh)
     uint32_t seed_lo, seed_hi;
     int64_t drop_row_base;      // added to the row index in the dropout counter
     const uint64_t *seed_dev;   // optional: the seed as of execution time (hipGraph replays)
@@ -481,6 +486,13 @@ template <int N> __device__ __forceinline__ void dma_wait()
 // they cost one drain of all earlier stores per column block); both persistent with the cross-tile pipeline.
 // EPI 1 (FWD_EPI): bias + ReLU + Philox dropout in the store; the Philox state would not fit next to
 // the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
+#ifdef GEMM_PROFILE_STAMPS   /* experiment builds only (tools/gemm_stamps_probe.py): where a tile's cycles go */
+__device__ unsigned long long g_gemm_stamps[8];
+#define GEMM_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); (v) = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GEMM_STAMP(v) do { } while (0)
+#endif
+
 template <int EPI, int SCH = 0>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
@@ -676,7 +688,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     w_issue(0, 0);
     x_issue(xsrc, 1, 1);
     dma_wait<4>();                 // X chunk 0 and this wave's part of W stage 0 are in LDS
-    {
+#ifndef GEMM_STAGGER
+#define GEMM_STAGGER 0
+#endif
+    // STAGGER (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per
+    // block"): waves w and w + 4 share a SIMD and, left alone, run in lockstep — both multiply, then
+    // both split the next step's X fragment (VALU) while the matrix pipe idles.  With the stagger
+    // waves 4-7 split a step's fragment at the TOP of the step (under the partner's MFMA run) and
+    // waves 0-3 at the bottom (under the partner's last MFMAs): same arithmetic, same results.
+    const bool late = GEMM_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (!late) {
         f32x4 lo, hi;
         a_read(0, 0, lo, hi);
         split_frag(lo, hi, row_ok);
@@ -692,7 +713,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     uint32_t vmax = 0u;   // max of |y| as BITS: unsigned order = float order for finite values, and
                           // inf / NaN patterns sort above every finite one (an overflow is never lost)
 
+    [[maybe_unused]] unsigned long long st_k = 0, st_s = 0, st_n = 0, st_a = 0, st_b = 0, st_c = 0, st_begin = 0;
+    GEMM_STAMP(st_begin);
     for (; tile < n_tiles; tile += gridDim.x) {
+        GEMM_STAMP(st_a);
 #ifndef GEMM_H2_EPI_PERSIST
 #define GEMM_H2_EPI_PERSIST 1
 #endif
@@ -761,6 +785,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
             }
 #endif
+#if GEMM_H2_XLDS
+            if (late) {
+                f32x4 lo, hi;
+                a_read(c & 1, (c >> 1) & 1, lo, hi);
+                split_frag(lo, hi, row_ok);
+                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
+                else asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#endif
             const u32x4 Xh = Ah, Xm = Am;
             [[maybe_unused]] const u32x4 Xl = Al;
             const unsigned char *buf = lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
@@ -816,7 +849,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             }
 #endif
 #if GEMM_H2_XLDS
-            if (c + 1 < kChunks || has_next) {
+            if (!late && (c + 1 < kChunks || has_next)) {
                 const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
                 f32x4 lo, hi;
                 a_read(cn & 1, (cn >> 1) & 1, lo, hi);
@@ -835,6 +868,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #endif
         }
 
+        GEMM_STAMP(st_b);
         if (row_ok) {
             float *yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
@@ -942,6 +976,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 if (DROP16) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        GEMM_STAMP(st_c);
+#ifdef GEMM_PROFILE_STAMPS
+        st_k += st_b - st_a;
+        st_s += st_c - st_b;
+        st_n += 1;
+#endif
         row = row_n;
         row_ok = ok_n;
         src_row = src_n;
@@ -957,6 +997,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
         if (lane == 0 && vmax != 0u) atomicMax(y_absmax, vmax);
     }
+#ifdef GEMM_PROFILE_STAMPS
+    if (lane == 0) {           // per wave: cycles in K loops / in store sections / tiles / whole lifetime
+        unsigned long long st_end;
+        GEMM_STAMP(st_end);
+        atomicAdd(&g_gemm_stamps[0], st_k);
+        atomicAdd(&g_gemm_stamps[1], st_s);
+        atomicAdd(&g_gemm_stamps[2], st_n);
+        atomicAdd(&g_gemm_stamps[3], st_end - st_begin);
+        atomicAdd(&g_gemm_stamps[4], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1649,6 +1700,16 @@ size_t gcn_gemm_xw256_h2_workspace_bytes(void)
     return (size_t)kH2HeaderBytes + (size_t)kChunks * kH2ChunkBytes;
 }
 
+#ifdef GEMM_PROFILE_STAMPS
+int gcn_debug_gemm_stamps(unsigned long long *out8, int reset)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_stamps), sizeof(z));
+    if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z));
+    return (int)e;
+}
+#endif
+
 size_t gcn_gemm_xw256_b3_workspace_bytes(void)
 {
     return (size_t)kH2HeaderBytes + (size_t)kChunks * SchemeK<1>::ChunkBytes;
@@ -1676,7 +1737,7 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
         ep.bias = epi->bias;
         ep.relu = epi->relu ? 1 : 0;
         ep.drop_thresh = gcn_dropout_threshold16(epi->dropout_p);
-        ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.drop_scale = gcn_dropout_scale16(ep.drop_thresh);
         ep.drop_row_base = epi->drop_row_base;
         ep.seed_lo = (uint32_t)epi->seed;
         ep.seed_hi = (uint32_t)(epi->seed >> 32);
@@ -1804,7 +1865,7 @@ int gcn_gemm_xw_bf16(const void *X, int64_t ldx, const void *W, int64_t ldw, voi
         ep.bias = epi->bias;
         ep.relu = epi->relu ? 1 : 0;
         ep.drop_thresh = gcn_dropout_threshold16(epi->dropout_p);
-        ep.drop_scale = 1.f / (1.f - epi->dropout_p);
+        ep.drop_scale = gcn_dropout_scale16(ep.drop_thresh);
         ep.drop_row_base = epi->drop_row_base;
         ep.seed_lo = (uint32_t)epi->seed;
         ep.seed_hi = (uint32_t)(epi->seed >> 32);

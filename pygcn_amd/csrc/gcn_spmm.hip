@@ -39,6 +39,13 @@ static inline uint32_t gcn_dropout_threshold16(float p)
     const double t = (double)p * 65536.0 + 0.5;
     return (uint32_t)std::min(65535.0, std::max(1.0, (double)(int64_t)t));
 }
+// the scale that goes with that threshold: the kernels keep an element with probability
+// (65536 - T) / 65536, so 65536 / (65536 - T) — not 1 / (1 - p) of the unquantised p — makes
+// E[dropout(x)] = x exactly (the two agree to 2^-17 away from the clamps, and exactly at p = 1/2)
+static inline float gcn_dropout_scale16(uint32_t thresh)
+{
+    return thresh == 0u ? 1.f : 65536.f / (float)(65536u - thresh);
+}
 
 namespace {
 
@@ -86,7 +93,7 @@ struct KParams {
     int32_t long_thresh;
     int32_t relu;
     uint32_t drop_thresh;   // keep an element iff its 16 random bits >= drop_thresh (0: no dropout)
-    float drop_scale;       // 1 / (1 - p)
+    float drop_scale;       // 65536 / (65536 - drop_thresh): 1 / (1 - p) of the quantised p
     uint32_t seed_lo, seed_hi;
     int64_t drop_row_base;  // added to the row index in the dropout counter (a shard's first row)
     const void *B2;          // optional second block of B: rows >= b_split live here (ldb2)
@@ -1546,7 +1553,7 @@ int gcn_spmm_csr_ep(const gcn_csr_plan *plan, int dtype, const void *B, int64_t 
     kp.relu = relu ? 1 : 0;
     // keep iff rand16 >= round(p * 2^16)  (p = 0 -> threshold 0 -> dropout off)
     kp.drop_thresh = gcn_dropout_threshold16(drop_p);
-    kp.drop_scale = 1.f / (1.f - drop_p);
+    kp.drop_scale = gcn_dropout_scale16(kp.drop_thresh);
     kp.drop_row_base = ep ? ep->drop_row_base : 0;
     kp.seed_lo = ep ? (uint32_t)ep->seed : 0u;
     kp.seed_hi = ep ? (uint32_t)(ep->seed >> 32) : 0u;

@@ -36,6 +36,10 @@ class NLLGrad(torch.Tensor):
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        if func is torch.ops.aten.isnan.default and len(args) == 1 and isinstance(args[0], NLLGrad):
+            # anomaly mode's NaN question (see rowgrad.RowGrad): the gradient's only non-zero values
+            # are copies of `coef` — answered without materialising [n, C]
+            return torch.isnan(args[0].coef)
         conv = lambda a: a.dense() if isinstance(a, NLLGrad) else a     # noqa: E731
         return func(*pytree.tree_map(conv, args), **pytree.tree_map(conv, kwargs or {}))
 

@@ -172,7 +172,7 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     """Forward pass shared by the one-node functions: (tensor saved in place of x, h1, logp).
     Fills ctx.scale / x_bound / z_bound / h_bound / reassoc / has_bias / bias_dtypes."""
     ctx.graph = graph
-    ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+    ctx.scale = _spmm.dropout_scale(dropout_p)
     # bounds of max|operand| for the scaled fp16 GEMMs (set_gemm_scheme("h2") only; the default
     # three-part bf16 GEMMs need none), without a pass over the data:
     # X is constant (cached), and |Â·B| <= ‖Â‖∞·max|B|

@@ -283,8 +283,8 @@ class CSRGraph:
         device planner (tests/test_ingest_gpu.py: array-for-array equality)."""
         return host_schedule(self.rowptr.cpu().numpy(), self.shape[0], self.item_cost, self.long_thresh)
 
-    def schedule_stats(self):
-        p = self.plan()
+    def schedule_stats(self, dtype=None):
+        p = self.plan(dtype)
         return {"n_items": int(p.n_items), "n_chunks": int(p.n_chunks), "n_long": int(p.n_long),
                 "long_thresh": int(p.long_thresh)}
 

@@ -44,6 +44,12 @@ class RowGrad(torch.Tensor):
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        if func is torch.ops.aten.isnan.default and len(args) == 1 and isinstance(args[0], RowGrad):
+            # anomaly mode (`torch.autograd.set_detect_anomaly(True)` around `backward()`, reference
+            # pygcn/policy-generator.py:419-420) asks every gradient a node returns whether it holds a
+            # NaN: answered on the compact rows — the structurally-zero rows hold none — so the
+            # [n, C] tensor is not materialised for the question
+            return torch.isnan(args[0].values)
         conv = lambda a: a.dense() if isinstance(a, RowGrad) else a     # noqa: E731
         return func(*pytree.tree_map(conv, args), **pytree.tree_map(conv, kwargs or {}))
 
@@ -86,6 +92,26 @@ class LossRows(torch.Tensor):
         return pytree.tree_map(lambda o: o.as_subclass(torch.Tensor) if isinstance(o, LossRows) else o, out)
 
 
+_NONNEG = {}     # rows_key of an index tensor -> are all its entries >= 0 (one host read per tensor)
+
+
+def _known_nonnegative(idx):
+    """`output[idx]` wraps negative indices, `index_select` (the structural route) does not — and on
+    ROCm its range assertion is compiled out.  Whether an index tensor is free of
+    negative entries is read ONCE per tensor identity (the row-set cache of pygcn_amd/fused.py
+    reads the same tensor on the host at that point anyway); a tensor with negative entries takes
+    the ordinary indexing path."""
+    from pygcn_amd.fused import rows_key
+    import weakref
+    key = rows_key(idx)
+    ent = _NONNEG.get(key)
+    if ent is None or ent[1]() is not idx:       # (an address reused by another tensor is not a hit)
+        if len(_NONNEG) >= 16:
+            _NONNEG.clear()
+        ent = _NONNEG[key] = (bool((idx >= 0).all()) if idx.numel() else True, weakref.ref(idx))
+    return ent[0]
+
+
 class RowSelectable(torch.Tensor):
     """Marker subclass of the model's output (see the module docstring)."""
 
@@ -96,7 +122,7 @@ class RowSelectable(torch.Tensor):
                 and isinstance(args[1], torch.Tensor) and not isinstance(args[1], RowSelectable)
                 and args[1].dim() == 1 and args[1].dtype == torch.int64 and args[0].dim() == 2
                 and args[0].requires_grad and torch.is_grad_enabled()
-                and args[1].device == args[0].device):
+                and args[1].device == args[0].device and _known_nonnegative(args[1])):
             return SelectRowsFunction.apply(args[0].as_subclass(torch.Tensor), args[1]).as_subclass(LossRows)
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)

@@ -58,7 +58,7 @@ import torch.distributed as dist
 
 from . import tuning
 from .graph import CSRGraph
-from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, pack_row_flags, rows_pack,
+from .spmm import (_dense_forward, _grad_pre_and_bias, _weight_grad, dropout_scale, pack_row_flags, rows_pack,
                    rows_unpack, spmm_csr, unpack_row_flags)
 
 
@@ -828,7 +828,7 @@ class ShardedSpMMFunction(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
         ctx.log_softmax = bool(log_softmax)
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = dropout_scale(dropout_p)
         out = sg.product(support_local, transpose=False, bias=bias, relu=relu,
                          dropout_p=dropout_p, seed=seed, log_softmax=log_softmax)
         if relu or log_softmax:
@@ -887,7 +887,7 @@ class ShardedHiddenLayerFunction(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.relu, ctx.log_softmax = bool(relu), bool(log_softmax)
         ctx.last_layer = bool(last_layer or log_softmax)
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = dropout_scale(dropout_p)
         from .spmm import known_absmax
         bound = known_absmax(h_local) if (h_local.is_cuda and h_local.dtype == torch.float32) else None
         out = sg.product_hidden(h_local, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed,
@@ -941,7 +941,7 @@ class ShardedInputLayerFunction(torch.autograd.Function):
         ctx.sg = sg
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = dropout_scale(dropout_p)
         ev = sg._tic(x_local)
         kw = {"dropout_p": dropout_p, "seed": seed, "row_base": sg.r0} if dropout_p > 0.0 else {}
         # REASSOCIATED where the GEMM kernel can carry the epilogue (256 -> 256 fp32, HIP):

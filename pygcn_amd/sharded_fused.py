@@ -112,7 +112,7 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sg, rs, x_local, x_halo, w1, b1, w2, b2, dropout_p, seed):
         ctx.sg, ctx.rs = sg, rs
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = _spmm.dropout_scale(dropout_p)
         f32 = x_local.dtype == torch.float32
         ev = sg._tic(x_local)
         z = sg._spmm(sg.A, x_local, tag="fwd_local", B2=x_halo)

@@ -377,6 +377,20 @@ def _grad_pre_and_bias(grad_out, out, relu, scale, want_bias, log_softmax=False,
     return grad_out, grad_bias, None
 
 
+def dropout_scale(p):
+    """1 / (keep probability) of the fused dropout at rate `p` — of the probability the kernels
+    actually keep with: the threshold is 16 bits, T = clamp(round(p · 65536), 1, 65535), an element
+    survives with probability (65536 − T) / 65536, and both the forward scale (C-ABI, struct
+    gcn_epilogue) and the backward mask scale are 65536 / (65536 − T), so E[dropout(x)] = x
+    exactly.  Equal to 1 / (1 − p) at p = 1/2 and within 2^-17 relative elsewhere."""
+    if not p > 0.0:
+        return 1.0
+    import numpy as np
+    t = int(np.float64(np.float32(p)) * 65536.0 + 0.5)
+    thresh = min(65535, max(1, t))
+    return float(np.float32(65536.0) / np.float32(65536 - thresh))
+
+
 def next_dropout_seed(device=None):
     """64-bit seed of one fused-dropout launch, drawn the way `F.dropout` draws on a GPU in the
     reference model (pygcn/models.py:50 upstream): from the DEVICE's default generator — its seed
@@ -442,7 +456,7 @@ class SpMMFunction(torch.autograd.Function):
         ctx.graph = graph
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = dropout_scale(dropout_p)
         out = spmm_csr(graph, B, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed)
         if relu:
             ctx.save_for_backward(out)
@@ -978,7 +992,7 @@ class GraphConvFunction(torch.autograd.Function):
         ctx.graph = graph
         ctx.relu = bool(relu)
         ctx.log_softmax = bool(log_softmax)
-        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        ctx.scale = dropout_scale(dropout_p)
         # (a layer input that needs no gradient is the constant feature matrix: its maximum is
         #  computed once and reused as the scaled GEMM's bound)
         # (bounds exist for the scaled fp16 scheme alone: the default three-part bf16 GEMMs need none)

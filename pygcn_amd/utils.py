@@ -217,3 +217,21 @@ def rmat_graph(n, n_edges, seed=42, perm_seed=43, device="cpu"):
     self-loops, row-normalized."""
     src, dst = rmat_edges(n, n_edges, seed=seed, device=device)
     return normalized_adjacency_csr(src, dst, n, perm_seed=perm_seed)
+
+
+def uniform_graph(n, degree=10, seed=46, device="cpu"):
+    """The CACHE-HOSTILE counterpart of the R-MAT graphs: every vertex draws
+    `degree` neighbours uniformly at random (seeded), duplicates removed, + I, row-normalized
+    (`normalize(adj + I)`, utils.py:368,390-397) — no hubs, so no dense-operand row is re-read often
+    enough for the 256 MiB Infinity Cache to matter: at 10^7 vertices x 1 KiB rows practically every
+    gather is an HBM miss.  Returns CSR arrays like rmat_graph."""
+    device = torch.device(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    row = torch.arange(n, device=device, dtype=torch.int64)
+    keys = [row * n + row]
+    for _ in range(degree):                       # (one column of neighbours at a time: O(n) temporaries)
+        keys.append(row * n + torch.randint(0, n, (n,), generator=gen, device=device, dtype=torch.int64))
+    key = torch.unique(torch.cat(keys))
+    del keys, row
+    return csr_from_keys(key, n, 0, n)

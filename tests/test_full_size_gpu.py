@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_normwise
+from conftest import assert_normwise, assert_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -99,15 +99,13 @@ def test_sampled_rows_of_the_transpose_product_against_oracle(c4, oracle):
     assert heaviest > 20000
     # Rows of Âᵀ are not normalized: a hub column sums 10⁴–10⁵ terms to magnitudes ~10², and the
     # float32 CPU chain loses ~1e-5 there by itself.  Arbiter: float64 accumulation of the same
-    # float32 products; the HIP result must be within the contract's 1e-5 of it, and within 2e-5 +
-    # (the float32 oracle's own distance from float64) of the float32 oracle.
+    # float32 products; the HIP result must be within the contract's 1e-5 of it, and within 1e-5 +
+    # (the float32 oracle's own measured distance from float64) of the float32 oracle
+    # (conftest.assert_parity).
     got = out[rows].cpu().numpy()
     ref64 = sampled_rows_reference(oracle, gt, G, rows, f64=True)
     ref32 = sampled_rows_reference(oracle, gt, G, rows)
-    assert_normwise(got, ref64, 1e-5, "C4 transpose product vs float64: sampled rows incl. the heaviest columns")
-    scale = np.abs(ref64).max()
-    e_oracle = np.abs(ref32.astype(np.float64) - ref64).max() / scale
-    assert np.abs(got.astype(np.float64) - ref32).max() / scale <= 2e-5 + e_oracle
+    assert_parity(got, ref32, ref64, "C4 transpose product: sampled rows incl. the heaviest columns")
 
 
 def test_transpose_block_equals_the_full_transpose_product(c4):
@@ -167,4 +165,5 @@ def test_training_step_routes_agree(c4):
         a, b = fused_grads[k].double(), p.grad.double()
         assert torch.isfinite(a).all() and float(b.abs().max()) > 0
         err = float((a - b).abs().max())
-        assert err <= 5e-5 * float(b.abs().max()), f"{k}: {err:.3e} vs {float(b.abs().max()):.3e}"
+        # (two float32 routes, each within the contract's 1e-5 of exact arithmetic)
+        assert err <= 2e-5 * float(b.abs().max()), f"{k}: {err:.3e} vs {float(b.abs().max()):.3e}"

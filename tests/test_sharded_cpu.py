@@ -418,3 +418,107 @@ def test_static_gradient_halo_and_transpose_block(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_rowsets_worker, args=(world, _free_port(), 900, 6000, str(tmp_path)), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def _selfcheck_worker(rank, world, port, out_dir, corrupt):
+    """pygcn_amd/selfcheck.py over gloo: healthy exchanges pass; a halo that is overwritten after
+    its wait (the symptom of a transfer that had not landed) and a gradient halo that loses its rows
+    must both be caught on EVERY rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import gcn_oracle
+    from pygcn_amd import GCN, selfcheck as sc
+    from pygcn_amd.sharded import ShardedGCN, ShardedGraph
+    from pygcn_amd.utils import rmat_graph
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, fin, nhid, ncls = 3000, 24, 32, 16
+        rowptr, col, val = rmat_graph(n, 24000, seed=7, device="cpu")
+        sg = ShardedGraph.from_global_csr(rowptr, col, val, n, rank, world, exchange="halo",
+                                          graph_factory=_CpuGraph, spmm_fn=_cpu_spmm, bwd_fn=_cpu_bwd,
+                                          overlap=True)
+        x = torch.from_numpy(np.random.default_rng(1).standard_normal((n, fin)).astype(np.float32))
+        labels = torch.from_numpy(np.random.default_rng(2).integers(0, ncls, n))
+        train = torch.from_numpy(np.sort(np.random.default_rng(3).choice(n, n // 5, False)))
+        x_loc, y_loc = x[sg.r0:sg.r1], labels[sg.r0:sg.r1]
+        idx_loc = train[(train >= sg.r0) & (train < sg.r1)] - sg.r0
+        torch.manual_seed(42)
+        model = GCN(fin, nhid, ncls, dropout=0.0)
+        smodel = ShardedGCN(model, sg)
+        model.train()
+        smodel.declare_loss_rows(idx_loc)
+        state = {}
+        if corrupt == "overlap" and rank == 1:
+            begin, end = sg.halo.exchange_begin, sg.halo.exchange_end
+
+            def bad_begin(local):
+                halo, pending = begin(local)
+                state["halo"] = halo
+                return halo, pending
+
+            def bad_end(pending):
+                end(pending)
+                if sg.overlap and state["halo"].shape[0]:          # pipelined form only: stale rows
+                    state["halo"][::2] = 123.0
+            sg.halo.exchange_begin, sg.halo.exchange_end = bad_begin, bad_end
+        ops = [x_loc[:, :ncls].contiguous() * (k + 1) for k in range(3)]
+        res = sc.overlap_selftest(sg, ops, tol=1e-5)
+        if corrupt == "overlap":
+            assert res["agrees"] is False and res["overlap_in_use"] is False and sg.overlap is False, res
+            assert res["max_err"] > 1e-3 and "fell back" in res["note"]
+        else:
+            assert res["agrees"] is True and sg.overlap is True and res["max_err"] <= 1e-5, res
+        # ---- gradient check: the sharded step vs the unsharded oracle step "on rank 0"
+        if corrupt == "gradient" and rank == 1:
+            sparse = sg.halo_t.exchange_sparse
+            sg.halo_t.exchange_sparse = lambda local, row_nonzero, static_key=None: \
+                torch.zeros_like(sparse(local, row_nonzero, static_key))       # the gradient rows are lost
+
+        def sharded_step():
+            model.zero_grad()
+            smodel.nll_loss(smodel(x_loc, sg), y_loc, idx_loc).backward()
+            smodel.allreduce_grads()
+
+        def reference_step():
+            a = gcn_oracle.CSR(rowptr.numpy(), col.numpy(), val.numpy(), (n, n))
+            p = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+            _, _, grads, _ = gcn_oracle.gcn2_loss_backward(x.numpy(), a, p, labels.numpy(), train.numpy())
+            return [torch.from_numpy(np.ascontiguousarray(grads[k])) for k, _ in model.named_parameters()]
+        res = sc.sharded_grad_check(list(model.parameters()), sharded_step, reference_step, tol=5e-5)
+        if corrupt == "gradient":
+            assert res["ok"] is False and res["max_err"] > 1e-3, res
+        else:
+            assert res["ok"] is True and res["max_err"] <= 5e-5 and len(res["per_param"]) == 4, res
+        # ---- the forward exchange A/B leaves every rank in the same (fastest) mode, all forms agree
+        if corrupt is None:
+            with torch.no_grad():
+                h1 = torch.relu(torch.from_numpy(np.random.default_rng(5 + rank).standard_normal(
+                    (sg.n_local, nhid)).astype(np.float32)))
+                ab = sc.forward_exchange_ab(sg, h1, model.gc2.weight, model.gc2.bias,
+                                            ["halo", "allgather", "rccl-allgather", "compress-hidden"],
+                                            reps=1, log_softmax=False)
+            assert set(ab["ms"]) == {"halo", "allgather", "rccl-allgather", "compress-hidden"}
+            assert all(v <= 1e-5 for v in ab["max_err_vs_first_mode"].values()), ab
+            chosen = [None] * world
+            dist.all_gather_object(chosen, (ab["chosen"], sg.fwd_exchange, sg.compress_hidden))
+            assert len(set(chosen)) == 1, chosen
+            lr = sc.link_rate(torch.device("cpu"), 1 << 20)
+            assert lr["gb_per_s"] > 0
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,corrupt", [(2, None), (3, None), (2, "overlap"), (3, "overlap"),
+                                           (2, "gradient"), (3, "gradient")])
+def test_multi_gpu_selfcheck_fires_on_a_corrupted_exchange(world, corrupt, tmp_path, oracle):
+    """the first run between GPUs validates itself (pygcn_amd/selfcheck.py,
+    called by bench.py at world > 1).  Healthy exchanges pass; a halo overwritten after its wait makes
+    the overlap self-test fall back to the unpipelined exchange on every rank; lost gradient rows
+    make the sharded gradient check fail on every rank."""
+    import torch.multiprocessing as mp
+    mp.spawn(_selfcheck_worker, args=(world, _free_port(), str(tmp_path), corrupt), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]

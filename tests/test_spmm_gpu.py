@@ -354,7 +354,7 @@ def test_fused_relu_dropout_epilogue_matches_philox_restatement(oracle, dev, F, 
     assert abs(keep.mean() - (1 - p)) < 0.03
     np.testing.assert_array_equal(out[~keep], 0.0)
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-6
-    np.testing.assert_allclose(out[keep], plain[keep] * np.float32(1.0 / (1.0 - p)), rtol=tol, atol=1e-30)
+    np.testing.assert_allclose(out[keep], plain[keep] * oracle.dropout_scale(p), rtol=tol, atol=1e-30)
     out2 = spmm_csr(g, B.to(dev), bias=torch.from_numpy(b).to(dev), relu=True, dropout_p=p,
                     seed=seed + 1).float().cpu().numpy()
     assert (out2 == 0).mean() != (out == 0).mean() or not np.array_equal(out2 == 0, out == 0)
@@ -380,7 +380,7 @@ def test_fused_dropout_autograd_and_model(oracle, dev):
     kept = yn != 0
     assert abs(kept[z > 0].mean() - (1 - p)) < 0.02 and not kept[z <= 0].any()
     np.testing.assert_allclose(yn[kept], (z / (1 - p))[kept], rtol=2e-5, atol=1e-6)
-    g_pre = np.where(kept, go / np.float32(1 - p), 0).astype(np.float32)
+    g_pre = np.where(kept, go * oracle.dropout_scale(p), 0).astype(np.float32)
     gx, gw, gb, _ = oracle.gc_backward(x, w, True, a, g_pre)
     _, gw64, gb64 = oracle.gc_backward_f64(x, w, True, a, g_pre, need_grad_x=False)
     assert_normwise(xg.grad.cpu(), gx, TOL, "grad_x")
