@@ -413,10 +413,11 @@ def main():
         # Per-rank memory is O(nnz / N) (+ one generator chunk), never the whole matrix.
         from pygcn_amd.sharded import ShardedGraph, ShardedGCN
         torch.cuda.reset_peak_memory_stats(dev)
-        # ("auto": built in halo mode — the constant-input halo and the static gradient halo of the
-        #  backward pass need it anyway — the forward exchange form is chosen by the A/B below)
+        # (always built in halo mode — the constant-input halo and the static gradient halo of the
+        #  backward pass need it — the hidden layer's FORWARD exchange form follows --exchange:
+        #  named explicitly, or chosen by the pre-timed A/B below)
         adj = ShardedGraph.from_rmat(n, e, rank, world, dev, seed=42, perm_seed=43,
-                                     exchange="halo" if args.exchange == "auto" else args.exchange,
+                                     exchange="halo",
                                      overlap=not args.no_overlap,
                                      compress_hidden=args.compress_hidden, **kw)
         torch.cuda.synchronize()
@@ -549,7 +550,8 @@ def main():
         tol_fwd = 1e-5 if dt == "f32" else 2.0 ** -6
         if not args.no_selfcheck:
             try:
-                selfcheck["link_rate"] = sc.link_rate(dev, min(1_280_000_000, max(1, n_local) * feat * esize))
+                # (the size must be the same number on both ends: max_rows, not this rank's n_local)
+                selfcheck["link_rate"] = sc.link_rate(dev, min(1_280_000_000, max(1, adj.max_rows) * feat * esize))
             except Exception as ex:
                 selfcheck["link_rate"] = {"error": repr(ex)}
             # (b) the pipelined exchange against the unpipelined one, on three different operands

@@ -470,10 +470,22 @@ __device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2,
 // (dma_wait<N>: N = DMA instructions issued AFTER the youngest one that must have landed — vector
 // loads complete in order, so "at most N outstanding" means everything older is in LDS; stores
 // that complete early only make the wait longer, never shorter).
+#ifndef GEMM_X_NT          /* experiment builds: 1 = the X stream (read once) is loaded non-temporally */
+#define GEMM_X_NT 0
+#endif
 __device__ __forceinline__ void dma16(const void *g, uint32_t lds_addr)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                  :: "v"(g), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_x(const void *g, uint32_t lds_addr)     // (the X stream)
+{
+#if GEMM_X_NT
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+                 :: "v"(g), "s"(lds_addr) : "memory", "m0");
+#else
+    dma16(g, lds_addr);
+#endif
 }
 template <int N> __device__ __forceinline__ void dma_wait()
 {
@@ -488,9 +500,21 @@ template <int N> __device__ __forceinline__ void dma_wait()
 // the next tile's prefetched fragments (spills), so this instantiation runs one tile per workgroup.
 #ifdef GEMM_PROFILE_STAMPS   /* experiment builds only (tools/gemm_stamps_probe.py): where a tile's cycles go */
 __device__ unsigned long long g_gemm_stamps[8];
+__device__ unsigned long long g_gemm_step_stamps[16];
+// (inside K steps 4 and 5 of every tile: cycles between seven points of the step, summed per wave)
+#define GEMM_STEP_STAMP(i)                                                             \
+    do {                                                                               \
+        if (c == 4 || c == 5) {                                                        \
+            unsigned long long t_;                                                     \
+            GEMM_STAMP(t_);                                                            \
+            if ((i) > 0) ph[8 * (c - 4) + (i)] += t_ - t_prev;                         \
+            t_prev = t_;                                                               \
+        }                                                                              \
+    } while (0)
 #define GEMM_STAMP(v) do { __builtin_amdgcn_sched_barrier(0); (v) = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GEMM_STAMP(v) do { } while (0)
+#define GEMM_STEP_STAMP(i) do { } while (0)
 #endif
 
 template <int EPI, int SCH = 0>
@@ -582,6 +606,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
         for (int i = 0; i < SK::WShare / 1024; ++i) dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
     };
+    [[maybe_unused]] auto w_issue_one = [&](int st, int b, int i) {           // (one of a stage's DMA instructions)
+        const unsigned char *src = wl + (size_t)st * kSchStageBytes + wave * SK::WShare + lane * 16;
+        dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
+    };
 #else
     u32x4 wreg[kH2WLoads];
     const unsigned char *wl = wimg;     // (re-made opaque per tile, see the tile loop)
@@ -614,7 +642,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     auto x_issue = [&](const float *const (&src)[4], int chunk, int slot) {
         const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)xl + slot * kXChunkBytes;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(src[j] + 32 * chunk, base + j * kXInstrBytes);
+        for (int j = 0; j < 4; ++j) dma16_x(src[j] + 32 * chunk, base + j * kXInstrBytes);
+    };
+    [[maybe_unused]] auto x_issue_one = [&](const float *const (&src)[4], int chunk, int slot, int j) {
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)xl + slot * kXChunkBytes;
+        dma16_x(src[j] + 32 * chunk, base + j * kXInstrBytes);
     };
     auto a_read = [&](int cstep, int slot, f32x4 &lo, f32x4 &hi) {
         const unsigned char *q = xl + slot * kXChunkBytes + rd_off + 512 * cstep;
@@ -713,7 +745,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     uint32_t vmax = 0u;   // max of |y| as BITS: unsigned order = float order for finite values, and
                           // inf / NaN patterns sort above every finite one (an overflow is never lost)
 
-    [[maybe_unused]] unsigned long long st_k = 0, st_s = 0, st_n = 0, st_a = 0, st_b = 0, st_c = 0, st_begin = 0;
+    [[maybe_unused]] unsigned long long st_k = 0, st_s = 0, st_n = 0, st_a = 0, st_b = 0, st_c = 0, st_begin = 0, st_f2 = 0, st_f8 = 0;
+    [[maybe_unused]] unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
     GEMM_STAMP(st_begin);
     for (; tile < n_tiles; tile += gridDim.x) {
         GEMM_STAMP(st_a);
@@ -745,15 +778,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             const int st = c / KS;
+            GEMM_STEP_STAMP(0);
 #if GEMM_H2_XLDS
             if (c % KS == 0) {
                 // every wave waited for ITS part of W stage st before it got here (end of the
                 // previous stage / prologue) and has read its last fragment of stage st - 1
                 __builtin_amdgcn_s_barrier();
-                if ((st + 1) * KS < kChunks)
-                    w_issue(st + 1, (st + 1) & 1);
-                else if (has_next)
-                    w_issue(0, 0);                                // the next tile's first stage
+                GEMM_STEP_STAMP(1);
+#ifndef GEMM_SPREAD_DMA
+#define GEMM_SPREAD_DMA 0
+#endif
+                // (SPREAD_DMA: the stage's DMA instructions are issued one by one between this step's
+                //  MFMA groups instead of as a burst behind the barrier — 8 waves x 3-7 instructions at
+                //  one point of time queue up in front of the CU's one address unit, and a wave that
+                //  cannot issue its DMA cannot issue its first MFMA either)
+                if (!GEMM_SPREAD_DMA) {
+                    if ((st + 1) * KS < kChunks)
+                        w_issue(st + 1, (st + 1) & 1);
+                    else if (has_next)
+                        w_issue(0, 0);                                // the next tile's first stage
+                }
             }
 #else
             if (c % kStage == 0) {
@@ -765,7 +809,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             }
 #endif
 #if GEMM_H2_XLDS
-            if (c & 1) {
+            if (!GEMM_SPREAD_DMA && (c & 1)) {
                 // chunk m = (c + 3) / 2 goes into the ring slot chunk m - 2 has just left (its last
                 // fragment was read at the end of step c - 1): three K steps of flight time
                 constexpr int kCh = kChunks / 2;
@@ -785,6 +829,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
             }
 #endif
+#ifndef GEMM_SPLIT_AHEAD
+#define GEMM_SPLIT_AHEAD 0
+#endif
+            GEMM_STEP_STAMP(2);
 #if GEMM_H2_XLDS
             if (late) {
                 f32x4 lo, hi;
@@ -792,6 +840,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 split_frag(lo, hi, row_ok);
                 if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
                 else asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#endif
+            // SPLIT AHEAD: the NEXT step's X fragment is already in LDS at the top of this step (b3:
+            // the wait that ends every step; h2: an extra counted wait at the end of even steps,
+            // below), so it is read here and split into its parts in four pieces BETWEEN this
+            // step's MFMA groups — VALU work that issues in the shadow of the wave's own MFMAs
+            // (the matrix pipe holds the vector issue for 8 of an MFMA's 32 cycles) instead of as
+            // one block between the last MFMA and the barrier, where the pipe idles.
+            [[maybe_unused]] f32x4 nlo, nhi;
+            [[maybe_unused]] uint32_t nh[4], nm[4], nl[4];
+            [[maybe_unused]] const bool have_next = GEMM_SPLIT_AHEAD && (c + 1 < kChunks || has_next);
+            [[maybe_unused]] const bool n_ok = c + 1 < kChunks ? row_ok : ok_n;
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+            if (have_next) {
+                const int cn = (c + 1) % kChunks;
+                a_read(cn & 1, (cn >> 1) & 1, nlo, nhi);
             }
 #endif
             const u32x4 Xh = Ah, Xm = Am;
@@ -808,7 +872,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
                 const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
                 f32x16 t = acc[nb];
-                __builtin_amdgcn_s_setprio(1);
+#ifndef GEMM_NO_SETPRIO    /* experiment builds */
+#define GEMM_NO_SETPRIO 0
+#endif
+                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);
                 if constexpr (SCH == 1) {
                     // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
                     const u32x4 Bl = Bf[nb & 1][NS - 1];
@@ -823,9 +890,66 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     t = mfma_h(Bh, Xm, t);
                     t = mfma_h(Bh, Xh, t);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 acc[nb] = t;
+                if (nb == 0) GEMM_STEP_STAMP(3);
+                if (nb == 3) GEMM_STEP_STAMP(4);
+                if (nb == 7) GEMM_STEP_STAMP(5);
+#if GEMM_H2_XLDS && GEMM_SPREAD_DMA
+                {
+                    // issue order as in the burst form (the counted waits depend on it): the stage's W
+                    // instructions first (on the step that opens a stage), then the X chunk's four (odd steps)
+                    constexpr int kWI = SK::WShare / 1024;
+                    const bool w_step = c % KS == 0;
+                    const int wi = w_step ? nb : -1;
+                    const int xi = (c & 1) ? nb - (w_step ? kWI : 0) : -1;
+                    if (wi >= 0 && wi < kWI) {
+                        if ((st + 1) * KS < kChunks)
+                            w_issue_one(st + 1, (st + 1) & 1, wi);
+                        else if (has_next)
+                            w_issue_one(0, 0, wi);
+                    }
+                    if (xi >= 0 && xi < 4) {
+                        constexpr int kCh = kChunks / 2;
+                        const int m = (c + 3) / 2;
+                        if (m < kCh)
+                            x_issue_one(xsrc, m, m & 1, xi);
+                        else if (has_next)
+                            x_issue_one(xsrc_n, m - kCh, m & 1, xi);
+                    }
+                }
+#endif
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+                if (have_next && (nb & 1)) {            // one pair of the next fragment per two column blocks
+                    const int j = nb >> 1;
+                    const float a0 = j == 0 ? nlo.x : (j == 1 ? nlo.z : (j == 2 ? nhi.x : nhi.z));
+                    const float a1 = j == 0 ? nlo.y : (j == 1 ? nlo.w : (j == 2 ? nhi.y : nhi.w));
+                    if constexpr (SCH == 1) {
+                        split3_pair(n_ok ? a0 : 0.f, n_ok ? a1 : 0.f, nh[j], nm[j], nl[j]);
+                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]), "+v"(nl[j]));
+                    } else {
+                        const float x0 = n_ok ? a0 * xs : 0.f, x1 = n_ok ? a1 * xs : 0.f;
+                        f32x2 v = {x0, x1};
+                        const h16x2 hh = __builtin_convertvector(v, h16x2);
+                        const f32x2 hb = __builtin_convertvector(hh, f32x2);
+                        f32x2 r = {x0 - hb.x, x1 - hb.y};
+                        const h16x2 mm = __builtin_convertvector(r, h16x2);
+                        nh[j] = __builtin_bit_cast(uint32_t, hh);
+                        nm[j] = __builtin_bit_cast(uint32_t, mm);
+                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]));
+                    }
+                }
+#endif
             }
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+            if (have_next) {
+                Ah = u32x4{nh[0], nh[1], nh[2], nh[3]};
+                Am = u32x4{nm[0], nm[1], nm[2], nm[3]};
+                if constexpr (SCH == 1) Al = u32x4{nl[0], nl[1], nl[2], nl[3]};
+            }
+            if (SCH == 0 && (c & 1) == 0 && (c + 2 < kChunks || has_next))
+                dma_wait<4>();      // (h2: the X chunk of step c + 2 has landed; only this step's W stage may still fly)
+#endif
 #if GEMM_H2_XLDS
             if (c % KS == KS - 1) {
                 // before the next stage: this wave's part of W stage st + 1 and the X chunk of the
@@ -849,7 +973,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             }
 #endif
 #if GEMM_H2_XLDS
-            if (!late && (c + 1 < kChunks || has_next)) {
+            GEMM_STEP_STAMP(6);
+#ifdef GEMM_PROFILE_STAMPS
+            if (c == 1) { unsigned long long t2; GEMM_STAMP(t2); st_f2 += t2 - st_a; }
+            if (c == 7) { unsigned long long t8; GEMM_STAMP(t8); st_f8 += t8 - st_a; }
+#endif
+            if (!GEMM_SPLIT_AHEAD && !late && (c + 1 < kChunks || has_next)) {
                 const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
                 f32x4 lo, hi;
                 a_read(cn & 1, (cn >> 1) & 1, lo, hi);
@@ -866,6 +995,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 asm volatile("" : "+v"(Ah), "+v"(Am));
             }
 #endif
+            GEMM_STEP_STAMP(7);
         }
 
         GEMM_STAMP(st_b);
@@ -961,7 +1091,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #ifdef GEMM_H2_ABLATE_STORES      /* ablation build only: keeps the arithmetic, drops the traffic */
                     if (v.x == 1.2345e-30f)
 #endif
+#if defined(GEMM_STORE_NT) && GEMM_STORE_NT      /* experiment builds: Y (written once) stored non-temporally */
+                    __builtin_nontemporal_store(v, (f32x4 *)(yrow + 32 * nb + 8 * g));
+#else
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
+#endif
                     if (y_absmax != nullptr) {                                 // (wave-uniform)
                         if (RELU)                    // stored values are >= 0 (or NaN): the bits as they are
                             vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
@@ -1006,6 +1140,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         atomicAdd(&g_gemm_stamps[2], st_n);
         atomicAdd(&g_gemm_stamps[3], st_end - st_begin);
         atomicAdd(&g_gemm_stamps[4], 1ull);
+        atomicAdd(&g_gemm_stamps[5], st_f2);
+        atomicAdd(&g_gemm_stamps[6], st_f8);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_gemm_step_stamps[i], ph[i]);
     }
 #endif
 }
@@ -1706,6 +1843,13 @@ int gcn_debug_gemm_stamps(unsigned long long *out8, int reset)
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_stamps), sizeof(z));
     if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof(z));
+    return (int)e;
+}
+int gcn_debug_gemm_step_stamps(unsigned long long *out16, int reset)
+{
+    unsigned long long z[16] = {0};
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_step_stamps), sizeof(z));
+    if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_step_stamps), z, sizeof(z));
     return (int)e;
 }
 #endif

@@ -91,6 +91,16 @@ def assert_parity(got, ref32, ref64, what="", rel=1e-5):
         f"{what}: vs float32 reference max|d|={err32:.3e} > ({rel:g}+{e_ref:.2e})*{scale:.3e}"
 
 
+@pytest.fixture
+def h2_scheme():
+    """The scaled two-part fp16 scheme (the one that HAS bounds of max|operand|), restored afterwards."""
+    from pygcn_amd import spmm as S
+    before = S.gemm_scheme()
+    S.set_gemm_scheme("h2")
+    yield
+    S.set_gemm_scheme(before)
+
+
 @pytest.fixture(params=["bf16x3", "h2"])
 def gemm_scheme(request):
     """Runs a test under both decompositions of the 256-wide fp32 GEMMs: "bf16x3" (the default,

@@ -17,16 +17,6 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture
-def h2_scheme():
-    """The scaled two-part fp16 scheme (the one that HAS a bound), restored afterwards."""
-    from pygcn_amd import spmm as S
-    before = S.gemm_scheme()
-    S.set_gemm_scheme("h2")
-    yield
-    S.set_gemm_scheme(before)
-
-
 def _run(scheme, X, W, bound=None):
     """Y through one of the two kernels; for "h2" the bound defaults to the exact max|X|."""
     from pygcn_amd import spmm as S

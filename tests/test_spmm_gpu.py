@@ -989,7 +989,7 @@ def test_output_row_selection(oracle, dev, F, dtype, idx64, density):
         spmm_csr(g, B, c_select=bits[:-1])
 
 
-def test_layer_output_carries_its_maximum_to_the_next_layer(dev):
+def test_layer_output_carries_its_maximum_to_the_next_layer(dev, h2_scheme):
     """The GEMM that ends a reassociated layer leaves max|out| for the tensor object it returns;
     the next layer's scaled GEMM picks it up instead of reducing over [N, 256] again.  The record is
     bound to the object AND its version."""

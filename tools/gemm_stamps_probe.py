@@ -22,6 +22,12 @@ bias = torch.randn(256, device=dev)
 xb = X.abs().max().reshape(1)
 
 
+def step_stamps(reset=True):
+    out = (ctypes.c_ulonglong * 16)()
+    assert L.gcn_debug_gemm_step_stamps(out, int(reset)) == 0
+    return list(out)
+
+
 def stamps(reset=True):
     out = (ctypes.c_ulonglong * 8)()
     assert L.gcn_debug_gemm_stamps(out, int(reset)) == 0
@@ -35,6 +41,7 @@ for scheme in ("bf16x3", "h2"):
             S.gemm_xw256(X, W, x_bound=xb, **kw)
         torch.cuda.synchronize()
         stamps()
+        step_stamps()
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
         e0.record()
         reps = 5
@@ -43,8 +50,14 @@ for scheme in ("bf16x3", "h2"):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        k, s, n, life, waves = stamps()[:5]
+        k, s, n, life, waves, f2, f8 = stamps()[:7]
         print(f"{scheme:7s} {name:18s} {ms:6.2f} ms | per wave-tile: K loop {k / n:8.0f} cyc, store section {s / n:8.0f} cyc "
               f"| wave lifetime {life / waves:10.0f} cyc = {life / waves / (ms * 1e-3 * reps) / 1e9 * reps:5.2f} GHz-equivalent "
-              f"| tiles per wave {n / waves:6.1f} | K share {k / life:.3f} store share {s / life:.3f}", flush=True)
+              f"| tiles per wave {n / waves:6.1f} | K share {k / life:.3f} store share {s / life:.3f} "
+              f"| K steps 0-1: {f2 / n / 2:6.0f} cyc/step, steps 2-7: {(f8 - f2) / n / 6:6.0f}, steps 8-15: {(k - f8) / n / 8:6.0f}", flush=True)
+        ph = step_stamps()
+        names = ["-", "barrier wait", "DMA issue", "frag reads + MFMA group 0", "groups 1-3", "groups 4-7", "vmcnt wait", "X read + split"]
+        for base, label in ((0, "step 4 (even)"), (8, "step 5 (odd) ")):
+            print("      " + label + ": " + ", ".join(f"{names[i]} {ph[base + i] / n:6.0f}" for i in range(1, 8))
+                  + f" | sum {sum(ph[base + 1:base + 8]) / n:6.0f}", flush=True)
 S.set_gemm_scheme("bf16x3")
