@@ -517,6 +517,22 @@ __device__ unsigned long long g_gemm_step_stamps[16];
 #define GEMM_STEP_STAMP(i) do { } while (0)
 #endif
 
+#ifdef GEMM_STAGGER
+#define GEMM_STAGGER_ON GEMM_STAGGER
+#else
+#define GEMM_STAGGER_ON 0
+#endif
+#ifdef GEMM_SPLIT_AHEAD
+#define GEMM_SPLIT_AHEAD_ON GEMM_SPLIT_AHEAD
+#else
+#define GEMM_SPLIT_AHEAD_ON 0
+#endif
+#ifdef GEMM_SPREAD_DMA
+#define GEMM_SPREAD_DMA_ON GEMM_SPREAD_DMA
+#else
+#define GEMM_SPREAD_DMA_ON 0
+#endif
+
 template <int EPI, int SCH = 0>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
@@ -544,7 +560,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // indices; kChunks % kH2Ring == 0 keeps slot = step % kH2Ring valid across the boundary.
     static_assert(kChunks % kH2Ring == 0, "the X ring must divide the K steps of a tile");
     static_assert(kChunks % KS == 0 && (kChunks / KS) % 2 == 0, "W stages must alternate evenly");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSchStageBytes];    // the two W stages
+#ifndef GEMM_B3_RING3
+#define GEMM_B3_RING3 0
+#endif
+    // R3 (the three-part scheme): THREE W stage buffers, a stage issued TWO steps ahead (at the top of
+    // step c for step c + 2, into the buffer the barrier has just freed), and the X chunks issued at
+    // the BOTTOM of even steps — see the K loop.
+    constexpr bool R3 = SCH == 1 && GEMM_B3_RING3 && GEMM_H2_XLDS;
+#ifndef GEMM_STORE_IN_LOOP
+#define GEMM_STORE_IN_LOOP 0
+#endif
+    constexpr bool SIL = R3 && GEMM_STORE_IN_LOOP && EPI != 2;      // (the masked form loads in its store section)
+    static_assert(!R3 || !(GEMM_STAGGER_ON || GEMM_SPLIT_AHEAD_ON || GEMM_SPREAD_DMA_ON), "R3 excludes the other pipeline experiments");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(R3 ? 3 : 2) * kSchStageBytes];    // the W stage buffers
 #if GEMM_H2_XLDS
     // (a separate LDS object, so the compiler's wait-count pass can tell a DMA into an X ring from
     //  a store into a W stage and does not drain the X prefetch at every W stage)
@@ -698,6 +726,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         src = ok ? (x_rows ? (int64_t)x_rows[row] : row) : 0;
     };
 
+    [[maybe_unused]] int wbuf = 0;              // R3: the buffer (0..2) of the current step's W stage
+    [[maybe_unused]] bool stored_prev = false;  // R3: the previous tile's store section issued its 32 stores
     int64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     int64_t row, src_row;
@@ -719,7 +749,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     x_issue(xsrc, 0, 0);
     w_issue(0, 0);
     x_issue(xsrc, 1, 1);
-    dma_wait<4>();                 // X chunk 0 and this wave's part of W stage 0 are in LDS
+    if constexpr (R3) {
+        w_issue(1, 1);
+        dma_wait<7>();             // X chunk 0 and W stage 0 landed; X chunk 1 and W stage 1 may still fly
+    } else {
+        dma_wait<4>();             // X chunk 0 and this wave's part of W stage 0 are in LDS
+    }
 #ifndef GEMM_STAGGER
 #define GEMM_STAGGER 0
 #endif
@@ -775,252 +810,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            const int st = c / KS;
-            GEMM_STEP_STAMP(0);
-#if GEMM_H2_XLDS
-            if (c % KS == 0) {
-                // every wave waited for ITS part of W stage st before it got here (end of the
-                // previous stage / prologue) and has read its last fragment of stage st - 1
-                __builtin_amdgcn_s_barrier();
-                GEMM_STEP_STAMP(1);
-#ifndef GEMM_SPREAD_DMA
-#define GEMM_SPREAD_DMA 0
-#endif
-                // (SPREAD_DMA: the stage's DMA instructions are issued one by one between this step's
-                //  MFMA groups instead of as a burst behind the barrier — 8 waves x 3-7 instructions at
-                //  one point of time queue up in front of the CU's one address unit, and a wave that
-                //  cannot issue its DMA cannot issue its first MFMA either)
-                if (!GEMM_SPREAD_DMA) {
-                    if ((st + 1) * KS < kChunks)
-                        w_issue(st + 1, (st + 1) & 1);
-                    else if (has_next)
-                        w_issue(0, 0);                                // the next tile's first stage
-                }
-            }
-#else
-            if (c % kStage == 0) {
-                __syncthreads();
-                if ((st + 1) * kStage < kChunks)
-                    w_load(st + 1);
-                else if (has_next)
-                    w_load(0);                                    // the next tile's first stage
-            }
-#endif
-#if GEMM_H2_XLDS
-            if (!GEMM_SPREAD_DMA && (c & 1)) {
-                // chunk m = (c + 3) / 2 goes into the ring slot chunk m - 2 has just left (its last
-                // fragment was read at the end of step c - 1): three K steps of flight time
-                constexpr int kCh = kChunks / 2;
-                const int m = (c + 3) / 2;
-                if (m < kCh)
-                    x_issue(xsrc, m, m & 1);
-                else if (has_next)
-                    x_issue(xsrc_n, m - kCh, m & 1);
-            }
-#else
-            {
-                constexpr int R = kH2Ring;
-                const int fc = c + R - 1;                         // step fetched now
-                if (fc < kChunks)
-                    a_fetch(xrow, fc, ar[fc % R][0], ar[fc % R][1]);
-                else if (has_next)
-                    a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
-            }
-#endif
-#ifndef GEMM_SPLIT_AHEAD
-#define GEMM_SPLIT_AHEAD 0
-#endif
-            GEMM_STEP_STAMP(2);
-#if GEMM_H2_XLDS
-            if (late) {
-                f32x4 lo, hi;
-                a_read(c & 1, (c >> 1) & 1, lo, hi);
-                split_frag(lo, hi, row_ok);
-                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
-                else asm volatile("" : "+v"(Ah), "+v"(Am));
-            }
-#endif
-            // SPLIT AHEAD: the NEXT step's X fragment is already in LDS at the top of this step (b3:
-            // the wait that ends every step; h2: an extra counted wait at the end of even steps,
-            // below), so it is read here and split into its parts in four pieces BETWEEN this
-            // step's MFMA groups — VALU work that issues in the shadow of the wave's own MFMAs
-            // (the matrix pipe holds the vector issue for 8 of an MFMA's 32 cycles) instead of as
-            // one block between the last MFMA and the barrier, where the pipe idles.
-            [[maybe_unused]] f32x4 nlo, nhi;
-            [[maybe_unused]] uint32_t nh[4], nm[4], nl[4];
-            [[maybe_unused]] const bool have_next = GEMM_SPLIT_AHEAD && (c + 1 < kChunks || has_next);
-            [[maybe_unused]] const bool n_ok = c + 1 < kChunks ? row_ok : ok_n;
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-            if (have_next) {
-                const int cn = (c + 1) % kChunks;
-                a_read(cn & 1, (cn >> 1) & 1, nlo, nhi);
-            }
-#endif
-            const u32x4 Xh = Ah, Xm = Am;
-            [[maybe_unused]] const u32x4 Xl = Al;
-            const unsigned char *buf = lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
-            u32x4 Bf[2][NS];
-            auto b_read = [&](int nb, u32x4 (&dst)[NS]) {
-#pragma unroll
-                for (int sp = 0; sp < NS; ++sp) dst[sp] = *(const u32x4 *)(buf + ((sp * 8 + nb) * 64 + lane) * 16);
-            };
-            b_read(0, Bf[0]);
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-                if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
-                const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
-                f32x16 t = acc[nb];
-#ifndef GEMM_NO_SETPRIO    /* experiment builds */
-#define GEMM_NO_SETPRIO 0
-#endif
-                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);
-                if constexpr (SCH == 1) {
-                    // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
-                    const u32x4 Bl = Bf[nb & 1][NS - 1];
-                    t = mfma(Bh, Xl, t);
-                    t = mfma(Bl, Xh, t);
-                    t = mfma(Bm, Xm, t);
-                    t = mfma(Bh, Xm, t);
-                    t = mfma(Bm, Xh, t);
-                    t = mfma(Bh, Xh, t);
-                } else {
-                    t = mfma_h(Bm, Xh, t);       // smaller terms first
-                    t = mfma_h(Bh, Xm, t);
-                    t = mfma_h(Bh, Xh, t);
-                }
-                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                acc[nb] = t;
-                if (nb == 0) GEMM_STEP_STAMP(3);
-                if (nb == 3) GEMM_STEP_STAMP(4);
-                if (nb == 7) GEMM_STEP_STAMP(5);
-#if GEMM_H2_XLDS && GEMM_SPREAD_DMA
-                {
-                    // issue order as in the burst form (the counted waits depend on it): the stage's W
-                    // instructions first (on the step that opens a stage), then the X chunk's four (odd steps)
-                    constexpr int kWI = SK::WShare / 1024;
-                    const bool w_step = c % KS == 0;
-                    const int wi = w_step ? nb : -1;
-                    const int xi = (c & 1) ? nb - (w_step ? kWI : 0) : -1;
-                    if (wi >= 0 && wi < kWI) {
-                        if ((st + 1) * KS < kChunks)
-                            w_issue_one(st + 1, (st + 1) & 1, wi);
-                        else if (has_next)
-                            w_issue_one(0, 0, wi);
-                    }
-                    if (xi >= 0 && xi < 4) {
-                        constexpr int kCh = kChunks / 2;
-                        const int m = (c + 3) / 2;
-                        if (m < kCh)
-                            x_issue_one(xsrc, m, m & 1, xi);
-                        else if (has_next)
-                            x_issue_one(xsrc_n, m - kCh, m & 1, xi);
-                    }
-                }
-#endif
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-                if (have_next && (nb & 1)) {            // one pair of the next fragment per two column blocks
-                    const int j = nb >> 1;
-                    const float a0 = j == 0 ? nlo.x : (j == 1 ? nlo.z : (j == 2 ? nhi.x : nhi.z));
-                    const float a1 = j == 0 ? nlo.y : (j == 1 ? nlo.w : (j == 2 ? nhi.y : nhi.w));
-                    if constexpr (SCH == 1) {
-                        split3_pair(n_ok ? a0 : 0.f, n_ok ? a1 : 0.f, nh[j], nm[j], nl[j]);
-                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]), "+v"(nl[j]));
-                    } else {
-                        const float x0 = n_ok ? a0 * xs : 0.f, x1 = n_ok ? a1 * xs : 0.f;
-                        f32x2 v = {x0, x1};
-                        const h16x2 hh = __builtin_convertvector(v, h16x2);
-                        const f32x2 hb = __builtin_convertvector(hh, f32x2);
-                        f32x2 r = {x0 - hb.x, x1 - hb.y};
-                        const h16x2 mm = __builtin_convertvector(r, h16x2);
-                        nh[j] = __builtin_bit_cast(uint32_t, hh);
-                        nm[j] = __builtin_bit_cast(uint32_t, mm);
-                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]));
-                    }
-                }
-#endif
-            }
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-            if (have_next) {
-                Ah = u32x4{nh[0], nh[1], nh[2], nh[3]};
-                Am = u32x4{nm[0], nm[1], nm[2], nm[3]};
-                if constexpr (SCH == 1) Al = u32x4{nl[0], nl[1], nl[2], nl[3]};
-            }
-            if (SCH == 0 && (c & 1) == 0 && (c + 2 < kChunks || has_next))
-                dma_wait<4>();      // (h2: the X chunk of step c + 2 has landed; only this step's W stage may still fly)
-#endif
-#if GEMM_H2_XLDS
-            if (c % KS == KS - 1) {
-                // before the next stage: this wave's part of W stage st + 1 and the X chunk of the
-                // next K step must be in LDS.  Younger than both: only the 4 DMA instructions of an
-                // X chunk issued at the top of THIS step (odd steps) — if they were.  (b3, one-step
-                // stages: on even steps the W stage just issued is the youngest — a full wait, 48
-                // MFMAs after its issue, the flight time h2's stages have too.)
-                constexpr int kCh = kChunks / 2;
-                const bool issued_x = (c & 1) && (((c + 3) / 2 < kCh) || has_next);
-                if (c + 1 < kChunks || has_next) {
-                    if (issued_x) dma_wait<4>();
-                    else dma_wait<0>();
-                }
-            }
-#else
-            if (c % kStage == kStage - 1) {
-                if (c + 1 < kChunks)
-                    w_store((st + 1) & 1);
-                else if (has_next)
-                    w_store(0);              // (stage kChunks/kStage would use buffer 0 too)
-            }
-#endif
-#if GEMM_H2_XLDS
-            GEMM_STEP_STAMP(6);
-#ifdef GEMM_PROFILE_STAMPS
-            if (c == 1) { unsigned long long t2; GEMM_STAMP(t2); st_f2 += t2 - st_a; }
-            if (c == 7) { unsigned long long t8; GEMM_STAMP(t8); st_f8 += t8 - st_a; }
-#endif
-            if (!GEMM_SPLIT_AHEAD && !late && (c + 1 < kChunks || has_next)) {
-                const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
-                f32x4 lo, hi;
-                a_read(cn & 1, (cn >> 1) & 1, lo, hi);
-                split_frag(lo, hi, c + 1 < kChunks ? row_ok : ok_n);
-                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
-                else asm volatile("" : "+v"(Ah), "+v"(Am));
-            }
-#else
-            if (c + 1 < kChunks) {
-                split_frag(ar[(c + 1) % kH2Ring][0], ar[(c + 1) % kH2Ring][1], row_ok);
-                asm volatile("" : "+v"(Ah), "+v"(Am));
-            } else if (has_next) {
-                split_frag(ar[0][0], ar[0][1], ok_n);
-                asm volatile("" : "+v"(Ah), "+v"(Am));
-            }
-#endif
-            GEMM_STEP_STAMP(7);
-        }
-
-        GEMM_STAMP(st_b);
-        if (row_ok) {
-            float *yrow = Y + row * ldy + 4 * (lane >> 5);
+        // ---- the store section of a tile, as two pieces: what is computed once per tile, and one
+        // column block's scaling / epilogue / four 16-byte stores.  They run after the K loop — or,
+        // with SIL (stores in the loop), column block by column block INSIDE the tile's last K step,
+        // right after the block's final MFMA: a store instruction costs the issuing wave ~50 cycles
+        // of address-unit time whatever it carries, 32 of them per wave at one point of the tile
+        // leave the matrix pipe idle for 12 000 cycles; spread under the last step's MFMA run they
+        // overlap it.
+        float *yrow = nullptr;
+        const float *mrow = nullptr;
+        uint32_t r1[4] = {0u, 0u, 0u, 0u};
+        f32x4 mk[2][4];                 // the mask of column block nb in mk[nb & 1]
+        auto store_prelude = [&]() {
+            yrow = Y + row * ldy + 4 * (lane >> 5);
             // optional fused backward of ReLU / dropout: y = mask_src[src_row] > 0 ? y * scale : 0
-            const float *mrow = MASKED ? mask_src + mask_row * ld_mask + 4 * (lane >> 5) : nullptr;
+            mrow = MASKED ? mask_src + mask_row * ld_mask + 4 * (lane >> 5) : nullptr;
             // dropout at p = 1/2: 128 one-bit keep fields per Philox call (gcn_spmm.hip,
             // apply_dropout) — ONE call covers all of this lane's 128 columns of the row
             // (block = this lane's half h; column 32nb + 8g + 4h + j is bit 16(nb & 1) + 4g + j of
             // word nb >> 1); other p: eight 16-bit fields per call, 16 calls per lane and tile
-            uint32_t r1[4] = {0u, 0u, 0u, 0u};
             if (DROP1) {
                 const int64_t drow = row + ep.drop_row_base;
                 uint32_t cw = (uint32_t)(lane >> 5);
                 asm volatile("" : "+v"(cw));
                 h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, seed_k0, seed_k1, r1);
             }
-            f32x4 mk[2][4];                 // the mask of column block nb in mk[nb & 1]
             if (MASKED) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) mk[0][g] = *(const f32x4 *)(mrow + 8 * g);
             }
-#pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
+        };
+        auto store_block = [&](int nb) {
+
                 // dropout: the two Philox calls of this column block (8 keep fields each: groups 0-1 and
                 // 2-3) are computed TOGETHER, so that their two dependent chains of quarter-rate
                 // 32 x 32 -> 64 multiplies interleave; the scheduling barrier below then sits between
@@ -1108,8 +929,296 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 // (keeps hipcc from running all 16 Philox chains of the tile side by side — 64 live
                 //  registers on top of the accumulators)
                 if (DROP16) __builtin_amdgcn_sched_barrier(0);
+            
+        };
+        if (SIL && row_ok) store_prelude();
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            const int st = c / KS;
+            GEMM_STEP_STAMP(0);
+#if GEMM_H2_XLDS
+            if (c % KS == 0) {
+                // every wave waited for ITS part of W stage st before it got here (end of the
+                // previous stage / prologue) and has read its last fragment of stage st - 1
+                __builtin_amdgcn_s_barrier();
+                GEMM_STEP_STAMP(1);
+#ifndef GEMM_SPREAD_DMA
+#define GEMM_SPREAD_DMA 0
+#endif
+                if constexpr (R3) {
+                    // the barrier has freed the buffer of stage c - 1 = (wbuf + 2) % 3: stage c + 2 goes
+                    // there now — two steps of flight (stages of the next tile are the same image)
+                    if (c + 2 < kChunks || has_next) {
+                        const int b2 = wbuf == 0 ? 2 : wbuf - 1;
+                        w_issue((c + 2) % kChunks, b2);
+                    }
+                } else
+                // (SPREAD_DMA: the stage's DMA instructions are issued one by one between this step's
+                //  MFMA groups instead of as a burst behind the barrier — 8 waves x 3-7 instructions at
+                //  one point of time queue up in front of the CU's one address unit, and a wave that
+                //  cannot issue its DMA cannot issue its first MFMA either)
+                if (!GEMM_SPREAD_DMA) {
+                    if ((st + 1) * KS < kChunks)
+                        w_issue(st + 1, (st + 1) & 1);
+                    else if (has_next)
+                        w_issue(0, 0);                                // the next tile's first stage
+                }
             }
+#else
+            if (c % kStage == 0) {
+                __syncthreads();
+                if ((st + 1) * kStage < kChunks)
+                    w_load(st + 1);
+                else if (has_next)
+                    w_load(0);                                    // the next tile's first stage
+            }
+#endif
+#if GEMM_H2_XLDS
+            if (!R3 && !GEMM_SPREAD_DMA && (c & 1)) {
+                // chunk m = (c + 3) / 2 goes into the ring slot chunk m - 2 has just left (its last
+                // fragment was read at the end of step c - 1): three K steps of flight time
+                constexpr int kCh = kChunks / 2;
+                const int m = (c + 3) / 2;
+                if (m < kCh)
+                    x_issue(xsrc, m, m & 1);
+                else if (has_next)
+                    x_issue(xsrc_n, m - kCh, m & 1);
+            }
+#else
+            {
+                constexpr int R = kH2Ring;
+                const int fc = c + R - 1;                         // step fetched now
+                if (fc < kChunks)
+                    a_fetch(xrow, fc, ar[fc % R][0], ar[fc % R][1]);
+                else if (has_next)
+                    a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
+            }
+#endif
+#ifndef GEMM_SPLIT_AHEAD
+#define GEMM_SPLIT_AHEAD 0
+#endif
+            GEMM_STEP_STAMP(2);
+#if GEMM_H2_XLDS
+            if (late) {
+                f32x4 lo, hi;
+                a_read(c & 1, (c >> 1) & 1, lo, hi);
+                split_frag(lo, hi, row_ok);
+                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
+                else asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#endif
+            // SPLIT AHEAD: the NEXT step's X fragment is already in LDS at the top of this step (b3:
+            // the wait that ends every step; h2: an extra counted wait at the end of even steps,
+            // below), so it is read here and split into its parts in four pieces BETWEEN this
+            // step's MFMA groups — VALU work that issues in the shadow of the wave's own MFMAs
+            // (the matrix pipe holds the vector issue for 8 of an MFMA's 32 cycles) instead of as
+            // one block between the last MFMA and the barrier, where the pipe idles.
+            [[maybe_unused]] f32x4 nlo, nhi;
+            [[maybe_unused]] uint32_t nh[4], nm[4], nl[4];
+            [[maybe_unused]] const bool have_next = GEMM_SPLIT_AHEAD && (c + 1 < kChunks || has_next);
+            [[maybe_unused]] const bool n_ok = c + 1 < kChunks ? row_ok : ok_n;
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+            if (have_next) {
+                const int cn = (c + 1) % kChunks;
+                a_read(cn & 1, (cn >> 1) & 1, nlo, nhi);
+            }
+#endif
+            const u32x4 Xh = Ah, Xm = Am;
+            [[maybe_unused]] const u32x4 Xl = Al;
+            const unsigned char *buf = R3 ? lds + wbuf * kSchStageBytes
+                                          : lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
+            u32x4 Bf[2][NS];
+            auto b_read = [&](int nb, u32x4 (&dst)[NS]) {
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) dst[sp] = *(const u32x4 *)(buf + ((sp * 8 + nb) * 64 + lane) * 16);
+            };
+            b_read(0, Bf[0]);
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+                if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
+                const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
+                f32x16 t = acc[nb];
+#ifndef GEMM_NO_SETPRIO    /* experiment builds */
+#define GEMM_NO_SETPRIO 0
+#endif
+                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                if constexpr (SCH == 1) {
+                    // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
+                    const u32x4 Bl = Bf[nb & 1][NS - 1];
+                    t = mfma(Bh, Xl, t);
+                    t = mfma(Bl, Xh, t);
+                    t = mfma(Bm, Xm, t);
+                    t = mfma(Bh, Xm, t);
+                    t = mfma(Bm, Xh, t);
+                    t = mfma(Bh, Xh, t);
+                } else {
+                    t = mfma_h(Bm, Xh, t);       // smaller terms first
+                    t = mfma_h(Bh, Xm, t);
+                    t = mfma_h(Bh, Xh, t);
+                }
+                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                acc[nb] = t;
+                if constexpr (SIL) {
+                    if (c == kChunks - 1 && row_ok) store_block(nb);
+                }
+                if (nb == 0) GEMM_STEP_STAMP(3);
+                if (nb == 3) GEMM_STEP_STAMP(4);
+                if (nb == 7) GEMM_STEP_STAMP(5);
+#if GEMM_H2_XLDS && GEMM_SPREAD_DMA
+                {
+                    // issue order as in the burst form (the counted waits depend on it): the stage's W
+                    // instructions first (on the step that opens a stage), then the X chunk's four (odd steps)
+                    constexpr int kWI = SK::WShare / 1024;
+                    const bool w_step = c % KS == 0;
+                    const int wi = w_step ? nb : -1;
+                    const int xi = (c & 1) ? nb - (w_step ? kWI : 0) : -1;
+                    if (wi >= 0 && wi < kWI) {
+                        if ((st + 1) * KS < kChunks)
+                            w_issue_one(st + 1, (st + 1) & 1, wi);
+                        else if (has_next)
+                            w_issue_one(0, 0, wi);
+                    }
+                    if (xi >= 0 && xi < 4) {
+                        constexpr int kCh = kChunks / 2;
+                        const int m = (c + 3) / 2;
+                        if (m < kCh)
+                            x_issue_one(xsrc, m, m & 1, xi);
+                        else if (has_next)
+                            x_issue_one(xsrc_n, m - kCh, m & 1, xi);
+                    }
+                }
+#endif
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+                if (have_next && (nb & 1)) {            // one pair of the next fragment per two column blocks
+                    const int j = nb >> 1;
+                    const float a0 = j == 0 ? nlo.x : (j == 1 ? nlo.z : (j == 2 ? nhi.x : nhi.z));
+                    const float a1 = j == 0 ? nlo.y : (j == 1 ? nlo.w : (j == 2 ? nhi.y : nhi.w));
+                    if constexpr (SCH == 1) {
+                        split3_pair(n_ok ? a0 : 0.f, n_ok ? a1 : 0.f, nh[j], nm[j], nl[j]);
+                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]), "+v"(nl[j]));
+                    } else {
+                        const float x0 = n_ok ? a0 * xs : 0.f, x1 = n_ok ? a1 * xs : 0.f;
+                        f32x2 v = {x0, x1};
+                        const h16x2 hh = __builtin_convertvector(v, h16x2);
+                        const f32x2 hb = __builtin_convertvector(hh, f32x2);
+                        f32x2 r = {x0 - hb.x, x1 - hb.y};
+                        const h16x2 mm = __builtin_convertvector(r, h16x2);
+                        nh[j] = __builtin_bit_cast(uint32_t, hh);
+                        nm[j] = __builtin_bit_cast(uint32_t, mm);
+                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]));
+                    }
+                }
+#endif
+            }
+#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
+            if (have_next) {
+                Ah = u32x4{nh[0], nh[1], nh[2], nh[3]};
+                Am = u32x4{nm[0], nm[1], nm[2], nm[3]};
+                if constexpr (SCH == 1) Al = u32x4{nl[0], nl[1], nl[2], nl[3]};
+            }
+            if (SCH == 0 && (c & 1) == 0 && (c + 2 < kChunks || has_next))
+                dma_wait<4>();      // (h2: the X chunk of step c + 2 has landed; only this step's W stage may still fly)
+#endif
+#if GEMM_H2_XLDS
+            if constexpr (R3) {
+                // Before the next step: this wave's part of W stage c + 1 (issued at the top of step
+                // c - 1) and the X fragment of step c + 1 must be in LDS.  Issued AFTER that stage, in
+                // order: the X chunk of the bottom of step c - 1 (c odd: 4), the previous tile's 32
+                // stores (c == 0), the stage issued at the top of this step (3) — all of them may
+                // still be in flight: vector-memory operations retire in order on one counter.
+                constexpr int kCh = kChunks / 2;
+                if (c + 1 < kChunks || has_next) {
+                    const bool w_top = (c + 2 < kChunks) || has_next;
+                    const bool x_prev = (c & 1) && (((c + 3) / 2 < kCh) || has_next);
+                    const bool st_prev = c == 0 && stored_prev;
+                    // (SIL: this tile's stores were issued DURING step 15, after everything step 16
+                    //  = the next tile's step 0 needs: they may all still be in flight at its bottom)
+                    const bool st_now = SIL && c == kChunks - 1 && __builtin_amdgcn_ballot_w64(row_ok) != 0ull;
+                    if (st_now) {                            // (c == 15 with a next tile: x_prev and w_top hold)
+                        dma_wait<39>();
+                    } else if (st_prev) {                    // (c == 0: x_prev is false)
+                        if (w_top) dma_wait<35>(); else dma_wait<32>();
+                    } else if (x_prev) {
+                        if (w_top) dma_wait<7>(); else dma_wait<4>();
+                    } else {
+                        if (w_top) dma_wait<3>(); else dma_wait<0>();
+                    }
+                }
+            } else
+            if (c % KS == KS - 1) {
+                // before the next stage: this wave's part of W stage st + 1 and the X chunk of the
+                // next K step must be in LDS.  Younger than both: only the 4 DMA instructions of an
+                // X chunk issued at the top of THIS step (odd steps) — if they were.  (b3, one-step
+                // stages: on even steps the W stage just issued is the youngest — a full wait, 48
+                // MFMAs after its issue, the flight time h2's stages have too.)
+                constexpr int kCh = kChunks / 2;
+                const bool issued_x = (c & 1) && (((c + 3) / 2 < kCh) || has_next);
+                if (c + 1 < kChunks || has_next) {
+                    if (issued_x) dma_wait<4>();
+                    else dma_wait<0>();
+                }
+            }
+#else
+            if (c % kStage == kStage - 1) {
+                if (c + 1 < kChunks)
+                    w_store((st + 1) & 1);
+                else if (has_next)
+                    w_store(0);              // (stage kChunks/kStage would use buffer 0 too)
+            }
+#endif
+#if GEMM_H2_XLDS
+            GEMM_STEP_STAMP(6);
+#ifdef GEMM_PROFILE_STAMPS
+            if (c == 1) { unsigned long long t2; GEMM_STAMP(t2); st_f2 += t2 - st_a; }
+            if (c == 7) { unsigned long long t8; GEMM_STAMP(t8); st_f8 += t8 - st_a; }
+#endif
+            if (!GEMM_SPLIT_AHEAD && !late && (c + 1 < kChunks || has_next)) {
+                const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
+                f32x4 lo, hi;
+                a_read(cn & 1, (cn >> 1) & 1, lo, hi);
+                split_frag(lo, hi, c + 1 < kChunks ? row_ok : ok_n);
+                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
+                else asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#else
+            if (c + 1 < kChunks) {
+                split_frag(ar[(c + 1) % kH2Ring][0], ar[(c + 1) % kH2Ring][1], row_ok);
+                asm volatile("" : "+v"(Ah), "+v"(Am));
+            } else if (has_next) {
+                split_frag(ar[0][0], ar[0][1], ok_n);
+                asm volatile("" : "+v"(Ah), "+v"(Am));
+            }
+#endif
+#if GEMM_H2_XLDS
+            if constexpr (R3) {
+                if ((c & 1) == 0) {
+                    // chunk m = (c + 4) / 2 goes into the ring slot whose chunk m - 2 has just given up
+                    // its last fragment (the read above): issued HERE, at the bottom of the step, where
+                    // a wave that has to queue behind the address unit waits beside its SIMD partner's
+                    // MFMA run instead of in front of its own
+                    constexpr int kCh = kChunks / 2;
+                    const int m = (c + 4) / 2;
+                    if (m < kCh)
+                        x_issue(xsrc, m, m & 1);
+                    else if (has_next)
+                        x_issue(xsrc_n, m - kCh, m & 1);
+                }
+                wbuf = wbuf == 2 ? 0 : wbuf + 1;
+            }
+#endif
+            GEMM_STEP_STAMP(7);
         }
+
+        GEMM_STAMP(st_b);
+        if (!SIL && row_ok) {
+            store_prelude();
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) store_block(nb);
+        }
+        // (R3's first wait of the next tile counts this tile's stores: exactly 32 per wave when any
+        //  lane stored — the masked instantiation also LOADS in its store section: not counted there,
+        //  its first wait then simply covers them)
+        stored_prev = !MASKED && __builtin_amdgcn_ballot_w64(row_ok) != 0ull;
         GEMM_STAMP(st_c);
 #ifdef GEMM_PROFILE_STAMPS
         st_k += st_b - st_a;
