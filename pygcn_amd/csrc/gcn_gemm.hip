@@ -1042,6 +1042,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #define GEMM_NO_SETPRIO 0
 #endif
                 if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#ifdef GEMM_MFMA16_HACK   /* THROUGHPUT PROBE ONLY — results are garbage: every 32x32x16 MFMA replaced by two
+                             16x16x32 MFMAs (same flops, same cycles) on the same operand registers, to see
+                             which clock the chip holds on the other shape inside THIS kernel (guide rule 28) */
+                if constexpr (SCH == 1) {
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const u32x4 Bl = Bf[nb & 1][NS - 1];
+                    f32x4v q0 = {t[0], t[1], t[2], t[3]}, q1 = {t[4], t[5], t[6], t[7]};
+                    f32x4v q2 = {t[8], t[9], t[10], t[11]}, q3 = {t[12], t[13], t[14], t[15]};
+                    auto m16 = [&](u32x4 a, u32x4 b, f32x4v c) {
+                        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+                    };
+                    q0 = m16(Bh, Xl, q0); q1 = m16(Bh, Xl, q1);
+                    q2 = m16(Bl, Xh, q2); q3 = m16(Bl, Xh, q3);
+                    q0 = m16(Bm, Xm, q0); q1 = m16(Bm, Xm, q1);
+                    q2 = m16(Bh, Xm, q2); q3 = m16(Bh, Xm, q3);
+                    q0 = m16(Bm, Xh, q0); q1 = m16(Bm, Xh, q1);
+                    q2 = m16(Bh, Xh, q2); q3 = m16(Bh, Xh, q3);
+                    t = f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+                } else
+#endif
                 if constexpr (SCH == 1) {
                     // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
                     const u32x4 Bl = Bf[nb & 1][NS - 1];
