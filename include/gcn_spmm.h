@@ -427,9 +427,12 @@ int gcn_gemm_xw256_f32_h2(const float *X, int64_t ldx, const int32_t *x_rows, co
  * (pygcn/layers.py:33) computes in fp32: both operands split into THREE bf16 parts (a 24-bit
  * significand, fp32's own), six bf16 MFMAs per product (every term down to 2^-16 of the leading
  * one; the dropped ones are <= 2^-24), fp32 accumulation.  bf16 has fp32's exponent range: no
- * scaling and no bound.  Same kernel pipeline and the same options as gcn_gemm_xw256_f32_h2 — x_rows,
- * y_absmax, the whole struct gcn_gemm_epilogue — and bit-identical results to gcn_gemm_xw256_f32
- * for the plain product.  Workspace >= gcn_gemm_xw256_b3_workspace_bytes().
+ * scaling and no bound.  The same options as gcn_gemm_xw256_f32_h2 — x_rows, y_absmax, the whole
+ * struct gcn_gemm_epilogue.  Two kernels behind it, both deterministic: contiguous rows (x_rows NULL;
+ * every epilogue but dropout at p != 1/2) run on 128-row tiles whose stores leave under the next
+ * tile's MFMAs (K summed in chunks of 32); a row list runs round 3's pipeline (K in chunks of 16,
+ * bit-identical to gcn_gemm_xw256_f32 for the plain product).  The two differ in fp32 summation
+ * order only (<= 1e-6 of a row's largest entry).  Workspace >= gcn_gemm_xw256_b3_workspace_bytes().
  */
 size_t gcn_gemm_xw256_b3_workspace_bytes(void);
 int gcn_gemm_xw256_f32_b3(const float *X, int64_t ldx, const int32_t *x_rows, const float *W,

@@ -629,10 +629,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const uint32_t w_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds +
                            __builtin_amdgcn_readfirstlane(wave) * SK::WShare;
     // this wave's eighth (h2: 4 KiB = 4 DMA instructions, b3: 3) of W stage `st` -> W buffer `b`
+#ifndef GEMM_ABLATE_WPIECES    /* ablation builds only (results garbage): DMA instructions per wave and W stage */
+#define GEMM_ABLATE_WPIECES (-1)
+#endif
+    [[maybe_unused]] bool ablate_first_tile = GEMM_ABLATE_WPIECES >= 0;
     auto w_issue = [&](int st, int b) {
         const unsigned char *src = wl + (size_t)st * kSchStageBytes + wave * SK::WShare + lane * 16;
+        constexpr int kPieces = GEMM_ABLATE_WPIECES >= 0 ? GEMM_ABLATE_WPIECES : SK::WShare / 1024;
 #pragma unroll
-        for (int i = 0; i < SK::WShare / 1024; ++i) dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
+        for (int i = 0; i < SK::WShare / 1024; ++i)      // (ablation: all pieces during a workgroup's FIRST tile, so
+            if (i < kPieces || ablate_first_tile)        //  that the stale W stages the later tiles multiply are real data)
+                dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
     };
     [[maybe_unused]] auto w_issue_one = [&](int st, int b, int i) {           // (one of a stage's DMA instructions)
         const unsigned char *src = wl + (size_t)st * kSchStageBytes + wave * SK::WShare + lane * 16;
@@ -788,6 +795,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #ifndef GEMM_H2_EPI_PERSIST
 #define GEMM_H2_EPI_PERSIST 1
 #endif
+        if (GEMM_ABLATE_WPIECES >= 0 && tile != (int64_t)blockIdx.x) ablate_first_tile = false;
         const bool has_next = (!FWD_EPI || GEMM_H2_EPI_PERSIST) && tile + gridDim.x < n_tiles;   // (uniform)
         // the W image's 32 load addresses are loop-invariant; left visible, hipcc hoists all of
         // them out of the tile loop as 64-bit VGPR pairs and spills 50 registers
@@ -1053,12 +1061,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     auto m16 = [&](u32x4 a, u32x4 b, f32x4v c) {
                         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
                     };
-                    q0 = m16(Bh, Xl, q0); q1 = m16(Bh, Xl, q1);
-                    q2 = m16(Bl, Xh, q2); q3 = m16(Bl, Xh, q3);
-                    q0 = m16(Bm, Xm, q0); q1 = m16(Bm, Xm, q1);
-                    q2 = m16(Bh, Xm, q2); q3 = m16(Bh, Xm, q3);
-                    q0 = m16(Bm, Xh, q0); q1 = m16(Bm, Xh, q1);
-                    q2 = m16(Bh, Xh, q2); q3 = m16(Bh, Xh, q3);
+                    // (twelve DISTINCT (A, B, accumulator) triples: identical ones would be merged by the compiler)
+                    q0 = m16(Bh, Xl, q0); q1 = m16(Bl, Xl, q1);
+                    q2 = m16(Bl, Xh, q2); q3 = m16(Bm, Xl, q3);
+                    q0 = m16(Bm, Xm, q0); q1 = m16(Bl, Xm, q1);
+                    q2 = m16(Bh, Xm, q2); q3 = m16(Bm, Xm, q3);
+                    q0 = m16(Bm, Xh, q0); q1 = m16(Bl, Xh, q1);
+                    q2 = m16(Bh, Xh, q2); q3 = m16(Bh, Xl, q3);
                     t = f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
                 } else
 #endif
@@ -1274,6 +1283,387 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         for (int i = 0; i < 16; ++i) atomicAdd(&g_gemm_step_stamps[i], ph[i]);
     }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// The three-part (fp32-equivalent) product with its STORES UNDER THE NEXT TILE'S MULTIPLICATIONS —
+// `gemm_xw256_s16_kernel` (round 4; contiguous rows; 6.2 ms against 7.05 at M = 10^7).
+//
+// Same arithmetic as gemm_xw256_h2_kernel<·, 1> (three bf16 parts per operand, six MFMAs per product,
+// smallest terms first).  What the ablations of that kernel say (profiles/r04_gemm_stamps.md): of its
+// 7.1 ms at M = 10^7 the W staging is worth 0.2 ms and the STORE SECTION 1.1 ms — 32 store
+// instructions per wave issued at one point of a tile, all eight waves at once, the matrix pipe idle
+// for 12 000 cycles; moving them inside the tile's last K step changed nothing (the step then takes
+// as long as the stores).  They can only hide under the multiplications of ANOTHER tile, which needs
+// the finished tile's result registers AND the running tile's accumulators — 2 x 128 — unless a
+// wave's tile is half as large.  So here:
+//
+//   * a workgroup tile is 128 rows, 16 per wave, on 16x16x32 MFMA tiles: lane (n = lane & 15,
+//     q = lane >> 4) owns output row n and, in column block cb (16 columns), columns 16cb + 4q .. +3
+//     (the transposed product again: W fragment as the A operand, X fragment as B; a lane stores
+//     16 bytes, a store instruction covers 16 rows x 64 contiguous bytes): 64 accumulator registers;
+//   * the previous tile's results stay in 64 registers (`prev`) and leave one column block at a time,
+//     two per K stage, BETWEEN the stage's MFMA groups;
+//   * NOTHING is issued as a burst (S16_SPREAD; the burst form of the same kernel runs 6.7 ms): behind
+//     column block 0 / 2 / 4 of a stage go two W pieces each, behind 6 the X chunk, behind 8 and 10 one
+//     store each, behind 12 the next chunk is waited for (a counted wait: it was issued a stage ago) and
+//     split into the other fragment set, under the last column blocks' MFMAs;
+//   * a W stage is one K chunk of 32 x all 256 columns x three parts (48 KiB, two buffers), so a
+//     128-row tile has 8 stages and a row costs as many barriers as before; the W image is re-read
+//     per 128 rows instead of per 256 (L2 hits; its whole cost was the 0.2 ms above);
+//   * X chunks are 16 rows x 32 columns (2 DMA instructions per wave), private to the wave, ring of 2,
+//     split ONCE per chunk into the three parts (12 registers, two sets).  Layout of one DMA
+//     instruction's KiB: [q 4][row 8][32 bytes] — lane (n, q) reads its 32 bytes at
+//     1040 (n >> 3) + 256 q + 32 (n & 7): the 16-byte slot index mod 16 is (n >> 3) + 2 (n & 7),
+//     distinct over each of ds_read_b128's 16-lane groups (MI355X_MICROARCH.md, LDS table);
+//   * every address is a uniform base (SGPR pair: tile origin, W stage) plus a 32-bit per-lane offset
+//     that never changes — no 64-bit address registers (the 16x16x32 form of the old pipeline spilled
+//     on them).  This needs contiguous X rows: row lists stay on gemm_xw256_h2_kernel<·, 1>, and so
+//     does dropout at p != 1/2 (sixteen Philox calls per tile keep hipcc from unrolling the stages).
+//
+// Sums run over 8 K chunks of 32 instead of 16 of 16: results differ from gemm_xw256_h2_kernel<·, 1>
+// (and round 1's kernel) in fp32 summation order — not bitwise, same accuracy against fp64.
+//
+// Measured and dropped on the way (profiles/r04_gemm_stamps.md): the same schedule on 32x32x16 MFMA
+// tiles with a wave tile of 32 rows x 128 columns (bit-identical to gemm_xw256_h2_kernel<·, 1>; an X
+// chunk shared by the two waves of a row group, ring of 3 behind the barrier): 7.8 ms as bursts,
+// 7.15 spread — no better than the kernel it was to replace; the 16x16x32 tiles on the OLD schedule
+// (8 waves x 32 rows, 256-row tiles): 7.03 against 7.06.
+constexpr int kT16StageBytes = 3 * 8 * kFragBytes;           // 24 KiB: K chunk of 32 x 128 columns x 3 parts
+constexpr int kT16Stages = 16;
+constexpr int kS16Rows = 16 * kWaves;                        // 128
+constexpr int kS16StageBytes = 2 * kT16StageBytes;           // 48 KiB: K chunk of 32 x 256 columns x 3 parts
+constexpr int kS16Stages = 8;
+constexpr int kS16XInstr = 1024 + 16;
+constexpr int kS16XChunk = 2 * kS16XInstr;                   // 16 rows x 32 columns fp32, padded
+constexpr int kS16XLds = kWaves * 2 * kS16XChunk;
+constexpr int kS16LdsBytes = 2 * kS16StageBytes + kS16XLds + kN * 4;      // W stages, X rings, bias
+
+// W [256][256] fp32 row-major -> [stage 16][part 3][cbi 8][lane 64][8 bf16]; stage = 2 kc + half;
+// element j of lane l: k = 32 kc + 8 (l >> 4) + j, n = 16 (8 half + cbi) + (l & 15)
+__global__ __launch_bounds__(256) void split_w_t16_kernel(const float *__restrict__ W, int64_t ldw,
+                                                          uint16_t *__restrict__ img)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one (stage, cbi, lane)
+    if (idx >= kT16Stages * 8 * 64) return;
+    const int lane = idx & 63, cbi = (idx >> 6) & 7, stage = idx >> 9;
+    const int n = 16 * (8 * (stage & 1) + cbi) + (lane & 15);
+    const int k0 = 32 * (stage >> 1) + 8 * (lane >> 4);
+    uint16_t h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(W[(int64_t)(k0 + j) * ldw + n], h[j], m[j], l[j]);
+    uint16_t *base = img + (size_t)stage * (kT16StageBytes / 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        base[((0 * 8 + cbi) * 64 + lane) * 8 + j] = h[j];
+        base[((1 * 8 + cbi) * 64 + lane) * 8 + j] = m[j];
+        base[((2 * 8 + cbi) * 64 + lane) * 8 + j] = l[j];
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                   c, 0, 0, 0);
+}
+
+// (HBM -> LDS, 16 bytes per lane, from a UNIFORM base + a 32-bit lane offset + an immediate.  The
+//  instruction's immediate offset is added to the global address AND to the LDS address: a piece at
+//  +OFF of its source lands at +OFF of `lds_addr`)
+template <int OFF> __device__ __forceinline__ void dma16_s(const void *sbase, uint32_t voff, uint32_t lds_addr)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr), "n"(OFF) : "memory", "m0");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
+    const float *__restrict__ X, int64_t ldx, const unsigned char *__restrict__ ws, float *__restrict__ Y,
+    int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
+{
+    // EPI as in gemm_xw256_h2_kernel: 0 plain, 2 backward mask, 1 bias, 4 + ReLU, 5 + dropout at 1/2, 6 + dropout at p
+    constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASKED = EPI == 2;
+    constexpr bool RELU = EPI >= 4, DROP1 = EPI == 5, DROP16 = EPI == 6;
+    static_assert(kWaves == 8, "written for eight waves");
+    constexpr int kSt = kS16StageBytes, kWShare = kSt / kWaves;          // a wave's part of a stage: 6 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char s16_lds[];   // [W stage 0][W stage 1][X rings][bias]
+    unsigned char *lds = s16_lds;
+    float *bias_lds = (float *)(s16_lds + 2 * kSt + kS16XLds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, q = lane >> 4;
+    const unsigned char *wl = ws + kH2HeaderBytes;
+    const int64_t n_tiles = (M + kS16Rows - 1) / kS16Rows;
+    const float *__restrict__ mask_src = ep.mask_src;
+    const int64_t ld_mask = ep.ld_mask;
+    const float mask_scale = ep.mask_scale;
+    uint32_t seed_k0 = ep.seed_lo, seed_k1 = ep.seed_hi;
+    if (FWD_EPI) {          // (bias into LDS, device seed read once: see gemm_xw256_h2_kernel)
+        if (tid < kN) bias_lds[tid] = ep.bias != nullptr ? ep.bias[tid] : 0.f;
+        if (ep.seed_dev != nullptr) {
+            const uint64_t sd = *ep.seed_dev;
+            seed_k0 = (uint32_t)sd;
+            seed_k1 = (uint32_t)(sd >> 32);
+        }
+        __syncthreads();
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s16_lds;
+    const uint32_t w_lds = lds0 + wave * kWShare;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+#ifndef S16_SPREAD       /* 0 (experiment builds): a stage's DMA and stores as a burst behind the barrier, its split at the end */
+#define S16_SPREAD 1
+#endif
+    // this wave's eighth of W stage `st` (6 DMA instructions; the immediate moves BOTH ends, see dma16_s): pieces 2 pr, 2 pr + 1
+    auto w_issue_pair = [&](int st, int b, int pr) {
+        const unsigned char *src = wl + (size_t)st * kSt + wave * kWShare;
+        const uint32_t dst = w_lds + b * kSt;
+        if (pr == 0) { dma16_s<0>(src, lane16, dst); dma16_s<1024>(src, lane16, dst); }
+        else if (pr == 1) { dma16_s<2048>(src, lane16, dst); dma16_s<3072>(src, lane16, dst); }
+        else { dma16_s<0>(src + 4096, lane16, dst + 4096); dma16_s<1024>(src + 4096, lane16, dst + 4096); }
+    };
+    auto w_issue = [&](int st, int b) { w_issue_pair(st, b, 0); w_issue_pair(st, b, 1); w_issue_pair(st, b, 2); };
+    unsigned char *xl = s16_lds + 2 * kSt + wave * (2 * kS16XChunk);
+    const uint32_t x_lds = lds0 + 2 * kSt + wave * (2 * kS16XChunk);
+    // what this lane FETCHES in DMA instruction j of a chunk: row 8j + ((lane >> 1) & 7) of the wave's 16,
+    // columns 8 (lane >> 4) + 4 (lane & 1) .. + 3 of the chunk's 32 — as a byte offset from the tile origin
+    const int ld_row = (lane >> 1) & 7;
+    const uint32_t xoff0 = (uint32_t)(((16 * wave + ld_row) * ldx + 8 * (lane >> 4) + 4 * (lane & 1)) * 4);
+    const uint32_t xoff1 = xoff0 + (uint32_t)(8 * ldx * 4);
+    auto x_issue = [&](int64_t t, int chunk, int slot) {
+        const float *src = X + t * kS16Rows * ldx + 32 * chunk;                         // (uniform)
+        const int lim = (int)min((int64_t)kS16Rows, M - t * kS16Rows) - 16 * wave;      // rows of this wave that exist
+        // (rows past the end of the matrix fetch the tile's first row instead: read, never stored)
+        dma16_s<0>(src, ld_row < lim ? xoff0 : 0u, x_lds + slot * kS16XChunk);
+        dma16_s<0>(src, ld_row + 8 < lim ? xoff1 : 0u, x_lds + slot * kS16XChunk + kS16XInstr);
+    };
+    // (where lane (n, q) READS its 32 bytes of a chunk)
+    const int rd16 = (n16 >> 3) * kS16XInstr + 256 * q + 32 * (n16 & 7);
+    u32x4 Xq[2][3];           // a chunk's fragment (parts h, m, l): stage c multiplies Xq[c & 1]
+    auto split_chunk = [&](int slot, u32x4 (&Xp)[3]) {
+        const unsigned char *p = xl + slot * kS16XChunk + rd16;
+        const f32x4 lo = *(const f32x4 *)p, hi = *(const f32x4 *)(p + 16);
+        const float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_pair(av[2 * j], av[2 * j + 1], h[j], m[j], l[j]);
+        Xp[0] = u32x4{h[0], h[1], h[2], h[3]};
+        Xp[1] = u32x4{m[0], m[1], m[2], m[3]};
+        Xp[2] = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    const int lrow = 16 * wave + n16;                                       // this lane's row in a tile
+    const uint32_t yoff = (uint32_t)(lrow * ldy + 4 * q);                   // floats from the tile origin
+
+    int64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    x_issue(tile, 0, 0);
+    w_issue(0, 0);
+    x_issue(tile, 1, 1);
+    dma_wait<2>();                 // X chunk 0 and this wave's part of W stage 0 are in LDS
+    split_chunk(0, Xq[0]);
+    uint32_t vmax = 0u;
+
+    // ---- one column block of a finished tile: epilogue + one 16-byte store per lane
+    f32x4 prev[16];               // the previous tile's results, leaving two column blocks per stage
+    int64_t ptile = 0;
+    bool have_prev = false;
+    [[maybe_unused]] uint32_t r1[4] = {0u, 0u, 0u, 0u};          // dropout at 1/2: the row's keep bits (one Philox call)
+    [[maybe_unused]] int64_t pmask_row = 0;                      // masked form: the mask row of this lane's prev row
+    auto finish = [&](int cb, f32x4 v, const f32x4 &mk, int64_t drow) __attribute__((always_inline)) -> f32x4 {
+        const int f = 16 * cb + 4 * q;                           // first of this lane's 4 columns
+        if (FWD_EPI) {
+            const f32x4 b4 = *(const f32x4 *)(bias_lds + f);
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (DROP1) {
+            // ONE Philox call per row and parity of bit 2 of the column covers this lane's 64 columns: column
+            // 16cb + 4q + j is bit 4 (2cb + (q >> 1)) + j of the call with block q & 1 (gcn_spmm.hip apply_dropout)
+            const uint32_t nib = r1[cb >> 2] >> (8 * (cb & 3) + 4 * (q >> 1));
+            v.x = (nib & 1u) ? v.x * ep.drop_scale : 0.f;
+            v.y = (nib & 2u) ? v.y * ep.drop_scale : 0.f;
+            v.z = (nib & 4u) ? v.z * ep.drop_scale : 0.f;
+            v.w = (nib & 8u) ? v.w * ep.drop_scale : 0.f;
+        } else if (DROP16) {
+            // eight 16-bit fields per call: block = (cb << 1) | (q & 1), this lane's four columns are fields 4 (q >> 1) .. + 3
+            uint32_t r4[4];
+            uint32_t cw = ((uint32_t)cb << 1) | (uint32_t)(q & 1);
+            asm volatile("" : "+v"(cw));
+            h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, seed_k0, seed_k1, r4);
+            const uint32_t w0 = (q & 2) ? r4[2] : r4[0], w1 = (q & 2) ? r4[3] : r4[1];
+            v.x = (w0 & 0xFFFFu) >= ep.drop_thresh ? v.x * ep.drop_scale : 0.f;
+            v.y = (w0 >> 16) >= ep.drop_thresh ? v.y * ep.drop_scale : 0.f;
+            v.z = (w1 & 0xFFFFu) >= ep.drop_thresh ? v.z * ep.drop_scale : 0.f;
+            v.w = (w1 >> 16) >= ep.drop_thresh ? v.w * ep.drop_scale : 0.f;
+        }
+        if (MASKED) {
+            v.x = mk.x > 0.f ? v.x * mask_scale : 0.f;
+            v.y = mk.y > 0.f ? v.y * mask_scale : 0.f;
+            v.z = mk.z > 0.f ? v.z * mask_scale : 0.f;
+            v.w = mk.w > 0.f ? v.w * mask_scale : 0.f;
+        }
+        if (y_absmax != nullptr) {                                 // (wave-uniform)
+            if (RELU)
+                vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
+                           max(__float_as_uint(v.z), __float_as_uint(v.w)));
+            else
+                vmax = max(max(vmax, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu)),
+                           max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu));
+        }
+        return v;
+    };
+    // what is needed once per finished tile: the row's dropout bits / its mask row
+    auto capture = [&](int64_t t) {
+        const int64_t row = t * kS16Rows + lrow;
+        if (DROP1) {
+            const int64_t drow = row + ep.drop_row_base;
+            uint32_t cw = (uint32_t)(q & 1);
+            asm volatile("" : "+v"(cw));
+            h2_philox((uint32_t)drow, (uint32_t)(drow >> 32), cw, 0u, seed_k0, seed_k1, r1);
+        }
+        if (MASKED) pmask_row = row >= M ? 0 : (ep.mask_rows != nullptr ? (int64_t)ep.mask_rows[row] : row);
+    };
+    [[maybe_unused]] f32x4 mk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // masked form: the next pair's masks
+    auto mask_load = [&](int pair) {
+        const float *mrow = mask_src + pmask_row * ld_mask + 4 * q + 32 * pair;
+        mk[0] = *(const f32x4 *)mrow;
+        mk[1] = *(const f32x4 *)(mrow + 16);
+    };
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const bool has_next = tile + gridDim.x < n_tiles;      // (uniform)
+        asm volatile("" : "+s"(wl));                           // (no hoisting of the W image's addresses)
+        f32x4 acc[16];
+#pragma unroll
+        for (int cb = 0; cb < 16; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < kS16Stages; ++c) {
+            // every wave waited for ITS part of stage c before it got here and has read its last
+            // fragment of stage c - 1
+            __builtin_amdgcn_s_barrier();
+            auto store_one = [&](int u) __attribute__((always_inline)) {  // column block 2c + u of the previous tile (always a full tile)
+                if (have_prev) {
+                    float *ybase = Y + ptile * kS16Rows * ldy;                          // (uniform)
+                    const int64_t drow = ptile * kS16Rows + lrow + ep.drop_row_base;
+                    const int cb = 2 * c + u;
+                    *(f32x4 *)(ybase + yoff + 16 * cb) = finish(cb, prev[cb], mk[u], drow);
+                }
+            };
+            auto stores = [&]() __attribute__((always_inline)) { store_one(0); store_one(1); };
+            // masked form: the masks were loaded a stage ago, and the compiler's wait for them must not
+            // see this stage's DMA (it cannot count inline-assembly loads): stores first, then the next
+            // pair's mask loads, then the DMA.  Other forms: DMA first, the stores are the youngest.
+            if (MASKED) {
+                stores();
+                if (c + 1 < kS16Stages) { if (have_prev) mask_load(c + 1); }
+            }
+            const bool issued_w = (c + 1 < kS16Stages) || has_next;
+            const bool issued_x = (c + 2 < kS16Stages) || has_next;
+            constexpr bool SPREAD = S16_SPREAD && !MASKED;
+            auto w_issue_all = [&]() {
+                if (c + 1 < kS16Stages) w_issue(c + 1, (c + 1) & 1);
+                else if (has_next) w_issue(0, 0);                // the next tile's first stage
+            };
+            auto issue_w_pair = [&](int pr) {
+                if (c + 1 < kS16Stages) w_issue_pair(c + 1, (c + 1) & 1, pr);
+                else if (has_next) w_issue_pair(0, 0, pr);
+            };
+            auto issue_x = [&]() {
+                if (c + 2 < kS16Stages)       // chunk c + 2 into the ring slot chunk c left (split a stage ago)
+                    x_issue(tile, c + 2, c & 1);
+                else if (has_next)
+                    x_issue(tile + gridDim.x, c + 2 - kS16Stages, c & 1);
+            };
+            if (!SPREAD) {
+                w_issue_all();
+                issue_x();
+                if (!MASKED) stores();
+            }
+            const unsigned char *buf = lds + (c & 1) * kSt;
+            const u32x4 (&Xp)[3] = Xq[c & 1];
+            u32x4 Bf[2][3];
+            auto b_read = [&](int cb, u32x4 (&dst)[3]) {
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    dst[sp] = *(const u32x4 *)(buf + (cb >> 3) * kT16StageBytes + ((sp * 8 + (cb & 7)) * 64 + lane) * 16);
+            };
+            b_read(0, Bf[0]);
+#pragma unroll
+            for (int cb = 0; cb < 16; ++cb) {
+                if (cb + 1 < 16) b_read(cb + 1, Bf[(cb + 1) & 1]);
+                const u32x4 Bh = Bf[cb & 1][0], Bm = Bf[cb & 1][1], Bl = Bf[cb & 1][2];
+                __builtin_amdgcn_s_setprio(1);
+                f32x4 t = acc[cb];
+                t = mfma16(Bh, Xp[2], t);      // smallest terms first
+                t = mfma16(Bl, Xp[0], t);
+                t = mfma16(Bm, Xp[1], t);
+                t = mfma16(Bh, Xp[1], t);
+                t = mfma16(Bm, Xp[0], t);
+                t = mfma16(Bh, Xp[0], t);
+                acc[cb] = t;
+                __builtin_amdgcn_s_setprio(0);
+                // SPREAD: nothing is issued as a burst.  Behind column block 0 / 2 / 4: two W pieces each;
+                // 6: the X chunk; 8, 10: one store each; 12: the next chunk (issued a stage ago) is waited
+                // for and split into the other fragment set, under the last column blocks' MFMAs.
+                if (SPREAD) {
+                    if (cb == 0 || cb == 2 || cb == 4) issue_w_pair(cb >> 1);
+                    if (cb == 6) issue_x();
+                    if (cb == 8) store_one(0);
+                    if (cb == 10) store_one(1);
+                    if (cb == 12 && issued_w) {
+                        // younger than the chunk's two DMA instructions (at least): this stage's 6 W pieces,
+                        // its X chunk and its stores
+                        if (issued_x) { if (have_prev) dma_wait<10>(); else dma_wait<8>(); }
+                        else { if (have_prev) dma_wait<8>(); else dma_wait<6>(); }
+                        split_chunk((c + 1) & 1, Xq[(c + 1) & 1]);
+                    }
+                }
+            }
+            // before the next stage: this wave's part of stage c + 1 and the next chunk (issued a stage
+            // ago) must be in LDS; younger than both: the X chunk issued in THIS stage and (unmasked
+            // forms) this stage's two stores
+            if (issued_w) {
+                if (!MASKED && have_prev) {
+                    if (issued_x) dma_wait<4>();
+                    else dma_wait<2>();
+                } else {
+                    if (issued_x) dma_wait<2>();
+                    else dma_wait<0>();
+                }
+                if (!SPREAD) split_chunk((c + 1) & 1, Xq[(c + 1) & 1]);
+                asm volatile("" : "+v"(Xq[(c + 1) & 1][0]), "+v"(Xq[(c + 1) & 1][1]), "+v"(Xq[(c + 1) & 1][2]));
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 16; ++cb) prev[cb] = acc[cb];
+        ptile = tile;
+        have_prev = true;
+        capture(tile);
+        if (MASKED && has_next) mask_load(0);
+    }
+
+    // ---- the last tile of this workgroup (the only one that can be partial): a plain store section
+    if (ptile * kS16Rows + lrow < M) {
+        float *ybase = Y + ptile * kS16Rows * ldy;
+        const int64_t drow = ptile * kS16Rows + lrow + ep.drop_row_base;
+#pragma unroll
+        for (int pair = 0; pair < 8; ++pair) {
+            if (MASKED) mask_load(pair);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cb = 2 * pair + u;
+                *(f32x4 *)(ybase + yoff + 16 * cb) = finish(cb, prev[cb], mk[u], drow);
+            }
+            if (DROP16) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (y_absmax != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+        if (lane == 0 && vmax != 0u) atomicMax(y_absmax, vmax);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2034,14 +2424,29 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
         ((uintptr_t)ep.bias) % 16 != 0)
         return gcn_internal_fail(GCN_E_ALIGN, "gcn_gemm_xw256_f32_h2: X / Y rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+#ifndef GEMM_B3_S16
+#define GEMM_B3_S16 1         /* 1: the three-part scheme on contiguous rows runs gemm_xw256_s16_kernel (128-row tiles, stores
+                                 under the next tile's MFMAs); 0: always gemm_xw256_h2_kernel<., 1> (bit-identical to round 1) */
+#endif
+    // instantiation by store section (compile-time options, see the kernels): 0 plain, 2 backward mask,
+    // 1 bias, 4 bias + ReLU, 5 + dropout at p = 1/2 (one-bit keep fields), 6 + dropout at another p
+    const bool fwd = ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u;
+    const int variant = !fwd ? (ep.mask_src != nullptr ? 2 : 0)
+                             : (!ep.relu ? 1 : (ep.drop_thresh == 0u ? 4 : (ep.drop_thresh == 32768u ? 5 : 6)));
+    // (s16 addresses a tile's rows as 32-bit offsets from the tile origin, takes no row list, and has no
+    //  instantiation for dropout at p != 1/2)
+    const bool s16 = sch == 1 && GEMM_B3_S16 && x_rows == nullptr && variant != 6 && ldx < (1 << 21) && ldy < (1 << 21);
     if (sch == 0)
         hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
+    else if (s16)
+        hipLaunchKernelGGL(split_w_t16_kernel, dim3(kT16Stages * 8 * 64 / 256), dim3(256), 0, s, W, ldw,
+                           (uint16_t *)((unsigned char *)workspace + kH2HeaderBytes));
     else      // (the three-part image of gemm_xw256_kernel, behind the same header space)
         hipLaunchKernelGGL(split_w_kernel, dim3(kChunks * 8 * 64 / 256), dim3(256), 0, s, W, ldw,
                            (uint16_t *)((unsigned char *)workspace + kH2HeaderBytes));
-    const int64_t tiles = (M + kTileRows - 1) / kTileRows;
+    const int64_t tiles = s16 ? (M + kS16Rows - 1) / kS16Rows : (M + kTileRows - 1) / kTileRows;
     // dynamic LDS of the X-through-LDS build: the two W stages + every wave's X ring (> 64 KiB)
-    const size_t dyn = GEMM_H2_XLDS ? (size_t)kXLdsBytes : 0;
+    const size_t dyn = s16 ? (size_t)kS16LdsBytes : (GEMM_H2_XLDS ? (size_t)kXLdsBytes : 0);
     if (dyn) {
         static bool raised = false;          // (idempotent; a benign race sets it twice)
         if (!raised) {
@@ -2052,23 +2457,28 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
                                  (const void *)gemm_xw256_h2_kernel<2, 1>, (const void *)gemm_xw256_h2_kernel<4, 1>,
                                  (const void *)gemm_xw256_h2_kernel<5, 1>, (const void *)gemm_xw256_h2_kernel<6, 1>};
             for (const void *k : all) {
-                hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kXLdsBytes);
                 if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_h2: LDS size");
+            }
+            const void *tall[] = {(const void *)gemm_xw256_s16_kernel<0>, (const void *)gemm_xw256_s16_kernel<1>,
+                                  (const void *)gemm_xw256_s16_kernel<2>, (const void *)gemm_xw256_s16_kernel<4>,
+                                  (const void *)gemm_xw256_s16_kernel<5>};
+            for (const void *k : tall) {
+                hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS16LdsBytes);
+                if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_b3: LDS size");
             }
             raised = true;
         }
     }
-    // instantiation by store section (compile-time options, see the kernel): 0 plain, 2 backward mask,
-    // 1 bias, 4 bias + ReLU, 5 + dropout at p = 1/2 (one-bit keep fields), 6 + dropout at another p
-    const bool fwd = ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u;
-    const int variant = !fwd ? (ep.mask_src != nullptr ? 2 : 0)
-                             : (!ep.relu ? 1 : (ep.drop_thresh == 0u ? 4 : (ep.drop_thresh == 32768u ? 5 : 6)));
     const unsigned grid = (fwd && !GEMM_H2_EPI_PERSIST) ? (unsigned)tiles : (unsigned)std::min<int64_t>(tiles, GEMM_H2_GRID);
 #define GCN_LAUNCH_H2(V)                                                                             \
     do {                                                                                             \
         if (sch == 0)                                                                                \
             hipLaunchKernelGGL((gemm_xw256_h2_kernel<V, 0>), dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows, \
                                (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep); \
+        else if (s16)                                                                                \
+            hipLaunchKernelGGL((gemm_xw256_s16_kernel<(V == 6 ? 5 : V)>), dim3(grid), dim3(kThreads), dyn, s, X, ldx, \
+                               (const unsigned char *)workspace, Y, ldy, M, (uint32_t *)y_absmax, ep);     \
         else                                                                                         \
             hipLaunchKernelGGL((gemm_xw256_h2_kernel<V, 1>), dim3(grid), dim3(kThreads), dyn, s, X, ldx, x_rows, \
                                (const unsigned char *)workspace, x_absmax_bound, Y, ldy, M, (uint32_t *)y_absmax, ep); \

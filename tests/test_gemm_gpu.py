@@ -35,11 +35,13 @@ def _run(scheme, X, W, bound=None):
 
 @pytest.mark.parametrize("M", [1, 257, 4099, 600_001])
 def test_three_part_pipeline_equals_the_round_one_kernel_bitwise(dev, M):
-    """gcn_gemm_xw256_f32_b3 (round 4: the fp32-equivalent scheme in the DMA / persistent pipeline)
-    issues the six MFMAs of a product in the order of round 1's gcn_gemm_xw256_f32: same bits, at
-    heights that give a persistent workgroup one ragged tile, several tiles, and a cross-tile
-    prefetch."""
-    from pygcn_amd import _native
+    """gcn_gemm_xw256_f32_b3 through a ROW LIST (gemm_xw256_h2_kernel<., 1>: the fp32-equivalent scheme
+    in round 3's DMA / persistent pipeline, 32x32x16 MFMAs) issues the six MFMAs of a product in the
+    order of round 1's gcn_gemm_xw256_f32: same bits, at heights that give a persistent workgroup one
+    ragged tile, several tiles, and a cross-tile prefetch.  Contiguous rows take gemm_xw256_s16_kernel
+    (16x16x32 MFMAs, K chunks of 32: another fp32 summation order, stores under the next tile's MFMAs):
+    held against the listed result to fp32 rounding of the ROW's scale, and bit-for-bit repeatable."""
+    from pygcn_amd import _native, spmm as S
     L = _native.lib()
     g = torch.Generator(device=dev).manual_seed(M)
     X = torch.randn(M, 256, generator=g, device=dev) * (10 ** (4 * torch.rand(M, 1, generator=g, device=dev) - 2))
@@ -49,8 +51,18 @@ def test_three_part_pipeline_equals_the_round_one_kernel_bitwise(dev, M):
     _native.check(L.gcn_gemm_xw256_f32(X.data_ptr(), X.stride(0), W.data_ptr(), W.stride(0), old.data_ptr(),
                                        old.stride(0), M, ws.data_ptr(), ws.numel(),
                                        torch.cuda.current_stream().cuda_stream), "gcn_gemm_xw256_f32")
+    before = S.gemm_scheme()
+    S.set_gemm_scheme("bf16x3")
+    try:
+        listed = S.gemm_xw256(X, W, rows=torch.arange(M, device=dev, dtype=torch.int32))
+    finally:
+        S.set_gemm_scheme(before)
+    assert torch.equal(listed, old)
     new = _run("bf16x3", X, W)
-    assert torch.equal(new, old)
+    err = (new.double() - old.double()).abs().amax(1)
+    scale = (X.double() @ W.double()).abs().amax(1)
+    assert bool((err <= 1e-6 * scale).all()), float((err / scale).max())
+    assert torch.equal(new, _run("bf16x3", X, W))           # (no atomics, fixed order: the same bits every run)
 
 
 @pytest.mark.parametrize("scheme", ["bf16x3", "h2"])
@@ -239,11 +251,17 @@ def test_gemm_with_row_list(dev, gemm_scheme):
     X = torch.randn(5000, 256, device=dev)
     W = torch.randn(256, 256, device=dev)
     rows = torch.randperm(5000, device=dev)[:1237].to(torch.int32)
-    want = gemm_xw256(X[rows.long()].contiguous(), W, x_bound=X.abs().max().reshape(1))
+    # (the three-part scheme runs listed and contiguous rows on two kernels with different fp32
+    #  summation orders: the bit-exact reference is the gathered matrix through an identity list)
+    Xg = X[rows.long()].contiguous()
+    ident = torch.arange(1237, device=dev, dtype=torch.int32)
+    want = gemm_xw256(Xg, W, x_bound=X.abs().max().reshape(1), rows=ident)
     Xp = torch.full_like(X, float("nan"))
     Xp[rows.long()] = X[rows.long()]
     got = gemm_xw256(Xp, W, x_bound=X.abs().max().reshape(1), rows=rows)
     assert got.shape == (1237, 256) and torch.equal(got, want)
+    dense = gemm_xw256(Xg, W, x_bound=X.abs().max().reshape(1))
+    assert_normwise(got.cpu(), dense.double().cpu().numpy(), 1e-6, "listed vs contiguous rows")
 
 
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 256), (256, 128)])
@@ -287,7 +305,9 @@ def test_gemm_with_fused_relu_dropout_mask(dev, gemm_scheme):
     assert torch.equal(got, want) and float(ymax) == float(want.abs().max())
     rows = torch.randperm(4000, device=dev)[:999].to(torch.int32)
     got_r = gemm_xw256(X, W, x_bound=b, rows=rows, mask_src=H, mask_scale=2.0)
-    assert torch.equal(got_r, want[rows.long()])
+    plain_r = gemm_xw256(X, W, x_bound=b, rows=rows)            # (the listed rows' own kernel, see test_gemm_with_row_list)
+    assert torch.equal(got_r, torch.where(H[rows.long()] > 0, plain_r * 2.0, torch.zeros_like(plain_r)))
+    assert_normwise(got_r.cpu(), want[rows.long()].double().cpu().numpy(), 1e-6, "listed vs contiguous rows")
 
 
 @pytest.mark.parametrize("p", [0.0, 0.3, 0.5])
@@ -303,7 +323,11 @@ def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p, gemm_scheme):
     W = torch.randn(256, 256, generator=gen, device=dev) * 0.1
     bias = torch.randn(256, generator=gen, device=dev)
     b = X.abs().max().reshape(1)
-    plain = gemm_xw256(X, W, x_bound=b)
+    # (three-part scheme: dropout at p != 1/2 has no instantiation of the contiguous-row kernel and
+    #  runs the listed rows' one — take the plain product from the same kernel)
+    from pygcn_amd import spmm as S
+    other = S.gemm_scheme() == "bf16x3" and p not in (0.0, 0.5)
+    plain = gemm_xw256(X, W, x_bound=b, rows=torch.arange(M, device=dev, dtype=torch.int32) if other else None)
     ident = CSRGraph(torch.arange(M + 1, device=dev, dtype=torch.int32),
                      torch.arange(M, device=dev, dtype=torch.int32), torch.ones(M, device=dev), (M, M))
     seed = 0x1234_5678_9ABC_DEF1
@@ -318,8 +342,9 @@ def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p, gemm_scheme):
         other = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=p, seed=seed + 1)
         assert not torch.equal(other, got)
     # bias only / relu only
-    assert torch.equal(gemm_xw256(X, W, x_bound=b, bias=bias), plain + bias)
-    assert torch.equal(gemm_xw256(X, W, x_bound=b, relu=True), plain.clamp_min(0))
+    dense = gemm_xw256(X, W, x_bound=b)
+    assert torch.equal(gemm_xw256(X, W, x_bound=b, bias=bias), dense + bias)
+    assert torch.equal(gemm_xw256(X, W, x_bound=b, relu=True), dense.clamp_min(0))
     # a device-resident seed gives the same mask as the same host seed
     sd = torch.tensor([seed & (2 ** 63 - 1)], dtype=torch.int64, device=dev)
     a1 = gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.25, seed=sd)
