@@ -1410,6 +1410,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s16_lds;
     const uint32_t w_lds = lds0 + wave * kWShare;
     const uint32_t lane16 = (uint32_t)lane * 16u;
+#ifndef S16_ABLATE        /* ablation builds only (results garbage): 1 no stores, 2 W staged during the first tile only, 4 X likewise */
+#define S16_ABLATE 0
+#endif
 #ifndef S16_SPREAD       /* 0 (experiment builds): a stage's DMA and stores as a burst behind the barrier, its split at the end */
 #define S16_SPREAD 1
 #endif
@@ -1548,7 +1551,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
                     float *ybase = Y + ptile * kS16Rows * ldy;                          // (uniform)
                     const int64_t drow = ptile * kS16Rows + lrow + ep.drop_row_base;
                     const int cb = 2 * c + u;
-                    *(f32x4 *)(ybase + yoff + 16 * cb) = finish(cb, prev[cb], mk[u], drow);
+                    const f32x4 v = finish(cb, prev[cb], mk[u], drow);
+                    if (!(S16_ABLATE & 1) || v.x == 1.2345e-30f) *(f32x4 *)(ybase + yoff + 16 * cb) = v;
                 }
             };
             auto stores = [&]() __attribute__((always_inline)) { store_one(0); store_one(1); };
@@ -1566,11 +1570,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
                 if (c + 1 < kS16Stages) w_issue(c + 1, (c + 1) & 1);
                 else if (has_next) w_issue(0, 0);                // the next tile's first stage
             };
+            const bool first_tile = tile == (int64_t)blockIdx.x;
             auto issue_w_pair = [&](int pr) {
+                if ((S16_ABLATE & 2) && !first_tile) return;
                 if (c + 1 < kS16Stages) w_issue_pair(c + 1, (c + 1) & 1, pr);
                 else if (has_next) w_issue_pair(0, 0, pr);
             };
             auto issue_x = [&]() {
+                if ((S16_ABLATE & 4) && !first_tile) return;
                 if (c + 2 < kS16Stages)       // chunk c + 2 into the ring slot chunk c left (split a stage ago)
                     x_issue(tile, c + 2, c & 1);
                 else if (has_next)
@@ -1607,12 +1614,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
                 // SPREAD: nothing is issued as a burst.  Behind column block 0 / 2 / 4: two W pieces each;
                 // 6: the X chunk; 8, 10: one store each; 12: the next chunk (issued a stage ago) is waited
                 // for and split into the other fragment set, under the last column blocks' MFMAs.
+#ifndef S16_SCHED         /* experiment builds: other placements of the same pieces (all issue in the same ORDER) */
+#define S16_SCHED 0
+#endif
+                // (column block behind which go: W pairs 0-2, the X chunk, store 0, store 1, the split)
+                constexpr int at[7] = {S16_SCHED == 0 ? 0 : S16_SCHED == 1 ? 1 : S16_SCHED == 2 ? 0 : 2,
+                                       S16_SCHED == 0 ? 2 : S16_SCHED == 1 ? 3 : S16_SCHED == 2 ? 1 : 4,
+                                       S16_SCHED == 0 ? 4 : S16_SCHED == 1 ? 5 : S16_SCHED == 2 ? 2 : 6,
+                                       S16_SCHED == 0 ? 6 : S16_SCHED == 1 ? 7 : S16_SCHED == 2 ? 4 : 8,
+                                       S16_SCHED == 0 ? 8 : S16_SCHED == 1 ? 9 : S16_SCHED == 2 ? 7 : 10,
+                                       S16_SCHED == 0 ? 10 : S16_SCHED == 1 ? 11 : S16_SCHED == 2 ? 10 : 12,
+                                       S16_SCHED == 0 ? 12 : S16_SCHED == 1 ? 13 : S16_SCHED == 2 ? 13 : 14};
                 if (SPREAD) {
-                    if (cb == 0 || cb == 2 || cb == 4) issue_w_pair(cb >> 1);
-                    if (cb == 6) issue_x();
-                    if (cb == 8) store_one(0);
-                    if (cb == 10) store_one(1);
-                    if (cb == 12 && issued_w) {
+                    if (cb == at[0]) issue_w_pair(0);
+                    if (cb == at[1]) issue_w_pair(1);
+                    if (cb == at[2]) issue_w_pair(2);
+                    if (cb == at[3]) issue_x();
+                    if (cb == at[4]) store_one(0);
+                    if (cb == at[5]) store_one(1);
+                    if (cb == at[6] && issued_w) {
                         // younger than the chunk's two DMA instructions (at least): this stage's 6 W pieces,
                         // its X chunk and its stores
                         if (issued_x) { if (have_prev) dma_wait<10>(); else dma_wait<8>(); }
