@@ -1458,6 +1458,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
 
     int64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    [[maybe_unused]] unsigned long long st_begin = 0, st_bw = 0, st_n = 0, st_a = 0, st_b = 0, st_loop_end = 0;
+    GEMM_STAMP(st_begin);
     x_issue(tile, 0, 0);
     w_issue(0, 0);
     x_issue(tile, 1, 1);
@@ -1545,7 +1547,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         for (int c = 0; c < kS16Stages; ++c) {
             // every wave waited for ITS part of stage c before it got here and has read its last
             // fragment of stage c - 1
+            GEMM_STAMP(st_a);
             __builtin_amdgcn_s_barrier();
+            GEMM_STAMP(st_b);
+            st_bw += st_b - st_a;
             auto store_one = [&](int u) __attribute__((always_inline)) {  // column block 2c + u of the previous tile (always a full tile)
                 if (have_prev) {
                     float *ybase = Y + ptile * kS16Rows * ldy;                          // (uniform)
@@ -1660,10 +1665,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         for (int cb = 0; cb < 16; ++cb) prev[cb] = acc[cb];
         ptile = tile;
         have_prev = true;
+        st_n += 1;
         capture(tile);
         if (MASKED && has_next) mask_load(0);
     }
 
+    GEMM_STAMP(st_loop_end);
     // ---- the last tile of this workgroup (the only one that can be partial): a plain store section
     if (ptile * kS16Rows + lrow < M) {
         float *ybase = Y + ptile * kS16Rows * ldy;
@@ -1684,6 +1691,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         for (int off = 32; off > 0; off >>= 1) vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
         if (lane == 0 && vmax != 0u) atomicMax(y_absmax, vmax);
     }
+#ifdef GEMM_PROFILE_STAMPS
+    if (lane == 0) {           // per wave: cycles waiting at the stage barriers / in the final store section / tiles / lifetime
+        unsigned long long st_end;
+        GEMM_STAMP(st_end);
+        atomicAdd(&g_gemm_stamps[0], st_bw);
+        atomicAdd(&g_gemm_stamps[1], st_end - st_loop_end);
+        atomicAdd(&g_gemm_stamps[2], st_n);
+        atomicAdd(&g_gemm_stamps[3], st_end - st_begin);
+        atomicAdd(&g_gemm_stamps[4], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
