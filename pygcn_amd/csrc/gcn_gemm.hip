@@ -2009,7 +2009,10 @@ constexpr int kAtgBufBytes = 2 * 2 * 8 * 2 * kFragBytes;   // [operand][MFMA ste
 // parts — the fp32-equivalent form, no bounds: its 96 KiB of fragments per super-step exist ONCE
 // (two buffers would not fit the LDS), so a second barrier separates multiply and publish.
 template <int SCH> constexpr int atg_buf_bytes() { return 2 * 2 * 8 * SchemeK<SCH>::NS * kFragBytes; }
-template <int SCH> constexpr int atg_lds_bytes() { return (SCH == 0 ? 2 : 1) * atg_buf_bytes<SCH>(); }
+#ifndef ATG_B3_STEP16
+#define ATG_B3_STEP16 1
+#endif
+template <int SCH> constexpr int atg_lds_bytes() { return SCH == 0 ? 2 * atg_buf_bytes<SCH>() : (ATG_B3_STEP16 ? 3 * atg_buf_bytes<SCH>() / 2 : atg_buf_bytes<SCH>()); }
 
 template <int SCH>
 __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
@@ -2020,6 +2023,8 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // 2 buffers of kAtgBufBytes
     const int tid = threadIdx.x, lane = tid & 63;
+    [[maybe_unused]] unsigned long long st_begin = 0;
+    GEMM_STAMP(st_begin);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int op = wave >> 2, w8 = wave & 3;            // operand streamed (0 A, 1 G); rows 8·w8 .. +7 of a super-step
     const int iw = wave & 3, jh = wave >> 2;            // result block: A tiles 2iw.., G tiles 4jh..
@@ -2114,6 +2119,137 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
         }
     };
 
+#ifndef ATG_B3_STEP16     /* 0 (experiment builds): the three-part scheme on 32-row super-steps in ONE buffer, two barriers each */
+#define ATG_B3_STEP16 1
+#endif
+    if constexpr (SCH == 1 && ATG_B3_STEP16) {
+        // Three parts per operand: a 32-row super-step's fragments are 96 KiB, two of them do not fit the LDS,
+        // and in one buffer publish (270 vector instructions per wave: the split into three bf16 parts) and
+        // multiply (96 MFMAs) alternate between two barriers with the matrix pipe idle for 45 % of the cycles
+        // (stamps: 11 200 cycles per 32 rows against 6 144 of MFMA time; this form: 9 170 — and 7.25 -> 7.05 ms,
+        // because the chip answers the denser pipe with a lower clock, 1.72 -> 1.59 GHz).  Here the unit of the LDS is ONE MFMA
+        // step of 16 rows (48 KiB) in a ring of THREE: a super-step's two steps are multiplied one per barrier
+        // interval, and during the SECOND interval every wave publishes its 8 rows of the NEXT super-step into
+        // the two buffers that are free then — two pair splits (12 VALU each) behind every block of six MFMAs,
+        // a tile's three fragment stores behind its fourth pair, fenced so that the order survives the
+        // scheduler (hipcc, left alone, gathers the vector work in one place): it issues in the shadow of the
+        // wave's own MFMAs and of its SIMD partner's.  Same MFMA order over the rows: the same bits as the
+        // one-buffer form.  One code path for every wave and every super-step (a step past the slab publishes
+        // zeros into a free buffer): the accumulators never cross a branch.
+        constexpr int kStepBytes = atg_buf_bytes<SCH>() / 2;            // [operand 2][tile 8][part 3][fragment]
+#ifndef ATG_B3_STAGGER    /* 1 (experiment builds): waves 4-7 split BEFORE a block's MFMAs, waves 0-3 behind them */
+#define ATG_B3_STAGGER 0
+#endif
+        const int st_of = w8 >> 1, kh = w8 & 1;                          // this wave's rows: step of the super-step, k-half
+        const bool late = wave >= 4;                                      // (uniform) the SIMD partner of wave - 4
+        const int64_t n_sup = s1 - s0;
+        f32x4 v[8];
+        auto fetch1 = [&](int64_t ss) {                        // loads only (rows of a super-step past the slab: its last)
+            ss = ss < s1 - 1 ? ss : s1 - 1;
+            int64_t pos = ss * 32 + 8 * w8;
+            pos = pos < padded - 8 ? pos : padded - 8;
+            const int32_t *idx = rows + pos;                    // (wave-uniform: one scalar load)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4 *)(src + (int64_t)idx[j] * ld);
+        };
+        auto pair_of = [&](int q, int j, int64_t k0, int64_t end, uint32_t &h_, uint32_t &m_, uint32_t &l_) __attribute__((always_inline)) {
+            const bool l0 = k0 + 2 * j < end, l1 = k0 + 2 * j + 1 < end;                  // (uniform)
+            const float a = q == 0 ? v[2 * j].x : (q == 1 ? v[2 * j].y : (q == 2 ? v[2 * j].z : v[2 * j].w));
+            const float c = q == 0 ? v[2 * j + 1].x : (q == 1 ? v[2 * j + 1].y : (q == 2 ? v[2 * j + 1].z : v[2 * j + 1].w));
+            split3_pair(l0 ? a : 0.f, l1 ? c : 0.f, h_, m_, l_);
+        };
+        // where this wave's fragments of a step buffer go: tile 2q + (lane >> 5) at + 2 q NS fragments
+        const int mine_off = (int)(((size_t)(op * 8 + (lane >> 5)) * NS) * kFragBytes) + ((lane & 31) + 32 * kh) * 16;
+        auto tile_store = [&](unsigned char *mine, int q, const uint32_t (&hh)[4], const uint32_t (&mm)[4], const uint32_t (&ll)[4]) __attribute__((always_inline)) {
+            unsigned char *tile = mine + (size_t)(2 * q) * NS * kFragBytes;
+            *(u32x4 *)(tile) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+            *(u32x4 *)(tile + kFragBytes) = u32x4{mm[0], mm[1], mm[2], mm[3]};
+            *(u32x4 *)(tile + 2 * kFragBytes) = u32x4{ll[0], ll[1], ll[2], ll[3]};
+        };
+        auto publish1 = [&](int64_t ss, unsigned char *dst) {   // (the prologue's: nothing to hide under yet)
+            const int64_t end = ss < s1 ? n_list : 0, k0 = ss * 32 + 8 * w8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pair_of(q, j, k0, end, hh[j], mm[j], ll[j]);
+                tile_store(dst + mine_off, q, hh, mm, ll);
+            }
+        };
+        // one 16-row step: 48 MFMAs per wave; PUBLISH: super-step `ss` goes out between the blocks
+        auto multiply1 = [&](const unsigned char *buf, const bool publish, int64_t ss, unsigned char *dst) __attribute__((always_inline)) {
+            const int64_t end = ss < s1 ? n_list : 0, k0 = ss * 32 + 8 * w8;
+            const unsigned char *gbase = buf + (size_t)8 * NS * kFragBytes;
+            uint32_t hh[4], mm[4], ll[4];
+            // (A tile outermost; the G fragments of block b + 1 are requested BEFORE block b's MFMAs — the fences
+            //  around the publish chunks would otherwise leave every block waiting for its own LDS reads)
+            u32x4 Af[NS], Bf[2][NS];
+            auto a_read = [&](int ib) __attribute__((always_inline)) {
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp)
+                    Af[sp] = *(const u32x4 *)(buf + (((2 * iw + ib) * NS + sp) * 64 + lane) * 16);
+            };
+            auto b_read = [&](int blk, u32x4 (&dst)[NS]) __attribute__((always_inline)) {
+                const unsigned char *gb = gbase + ((4 * jh + (blk & 3)) * NS) * kFragBytes;
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) dst[sp] = *(const u32x4 *)(gb + (sp * 64 + lane) * 16);
+            };
+            a_read(0);
+            b_read(0, Bf[0]);
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                const int ib = blk >> 2, jb = blk & 3;
+                if (blk == 4) a_read(1);
+                if (blk + 1 < 8) b_read(blk + 1, Bf[(blk + 1) & 1]);
+                const u32x4 Bh = Bf[blk & 1][0], Bm = Bf[blk & 1][1], Bl = Bf[blk & 1][2];
+                // block b = 4 ib + jb: for tile q = b >> 1 the pairs (rows 2j, 2j + 1), j = 2 (b & 1), + 1.
+                // (STAGGER, measured and left off — 10 280 cycles per 32 rows against 9 170: waves 4-7 take a
+                //  block's vector work BEFORE its MFMAs, waves 0-3 after, so that SIMD partners alternate;
+                //  the branches are uniform and hold no accumulator)
+                const int q = blk >> 1;
+                auto chunk = [&]() __attribute__((always_inline)) {
+                    pair_of(q, 2 * (blk & 1), k0, end, hh[2 * (blk & 1)], mm[2 * (blk & 1)], ll[2 * (blk & 1)]);
+                    pair_of(q, 2 * (blk & 1) + 1, k0, end, hh[2 * (blk & 1) + 1], mm[2 * (blk & 1) + 1], ll[2 * (blk & 1) + 1]);
+                    if (blk & 1) tile_store(dst + mine_off, q, hh, mm, ll);
+                };
+                if (publish) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ATG_B3_STAGGER && late) chunk();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                f32x16 t = acc[ib][jb];
+                t = mfma(Af[0], Bl, t);        // smallest terms first
+                t = mfma(Af[2], Bh, t);
+                t = mfma(Af[1], Bm, t);
+                t = mfma(Af[0], Bm, t);
+                t = mfma(Af[1], Bh, t);
+                t = mfma(Af[0], Bh, t);
+                acc[ib][jb] = t;
+                if (publish) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ATG_B3_STAGGER && late)) chunk();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if (n_sup > 0) {                                        // (uniform over the workgroup)
+            // ring of three step buffers (byte offsets): e = the super-step's first step, o = its second, p = free
+            int e = 0, o = kStepBytes, p = 2 * kStepBytes;
+            fetch1(s0);
+            publish1(s0, lds + (st_of ? o : e));
+            fetch1(s0 + 1);
+            __syncthreads();
+            for (int64_t i = 0; i < n_sup; ++i) {
+                multiply1(lds + e, false, 0, nullptr);
+                __syncthreads();                                // (everyone has left buffer e: the next super-step's second step goes there)
+                multiply1(lds + o, true, s0 + i + 1, lds + (st_of ? e : p));
+                fetch1(s0 + i + 2);
+                __syncthreads();
+                const int e2 = p, o2 = e, p2 = o;
+                e = e2; o = o2; p = p2;
+            }
+        }
+    } else
     if (s0 < s1) {                                               // (uniform over the workgroup)
 #pragma unroll
         for (int d = 0; d < kAtgDepth; ++d) {
@@ -2173,6 +2309,14 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
             }
         }
     }
+#ifdef GEMM_PROFILE_STAMPS
+    if (lane == 0) {           // per wave: lifetime of the row loop (the 256 x 256 partial result is stored after it)
+        unsigned long long st_end;
+        GEMM_STAMP(st_end);
+        atomicAdd(&g_gemm_stamps[3], st_end - st_begin);
+        atomicAdd(&g_gemm_stamps[4], 1ull);
+    }
+#endif
     // D[i][j] of tiles (Ta, Tb): i = (reg&3) + 8*(reg>>2) + 4*(lane>>5), j = lane&31;
     // column of tile T, slot u: 128*(T&1) + 4*u + (T>>1)
     float *out = partial + (size_t)blockIdx.x * (kK * kN);
