@@ -556,16 +556,31 @@ def test_dma_pipeline_is_deterministic_across_tiles_and_launches(dev, gemm_schem
         b = X.abs().max().reshape(1)
         rows = torch.randint(0, M, (M // 2,), device=dev, dtype=torch.int32)
         H = torch.relu(torch.randn(M, 256, device=dev))
+        perm = torch.randperm(M, device=dev).to(torch.int32)
         variants = {
             "plain": lambda: gemm_xw256(X, W, x_bound=b),
             "epilogue": lambda: gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.3, seed=99),
+            # (the contiguous-row kernel of the three-part scheme has its own store sections: dropout at 1/2,
+            #  the backward mask read at the row and through a mask row list)
+            "epilogue 1/2": lambda: gemm_xw256(X, W, x_bound=b, bias=bias, relu=True, dropout_p=0.5, seed=98),
+            "mask": lambda: gemm_xw256(X, W, x_bound=b, mask_src=H, mask_scale=1.5),
+            "mask rows": lambda: gemm_xw256(X, W, x_bound=b, mask_src=H, mask_rows=perm, mask_scale=1.5),
             "rows+mask": lambda: gemm_xw256(X, W, x_bound=b, rows=rows, mask_src=H, mask_scale=1.5),
         }
+        results = {}
         for name, fn in variants.items():
             first = fn()
+            results[name] = first
             assert torch.isfinite(first).all(), (name, M)
             for _ in range(12):
                 assert torch.equal(fn(), first), (name, M)
+        plain = results["plain"]
+        assert torch.equal(results["mask"], torch.where(H > 0, plain * 1.5, torch.zeros_like(plain))), M
+        assert torch.equal(results["mask rows"], torch.where(H[perm.long()] > 0, plain * 1.5, torch.zeros_like(plain))), M
+        keep = results["epilogue 1/2"] != 0
+        want = ((plain + bias).clamp_min(0) * 2.0)
+        assert torch.equal(results["epilogue 1/2"][keep], want[keep]), M
+        assert 0.2 < keep.float().mean().item() < 0.3, M          # ~half survive the ReLU, half of those the dropout
         ref = X[:2048].double() @ W.double()
         got = variants["plain"]()[:2048].double()
         assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-6
