@@ -315,7 +315,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 // X THROUGH LDS BY DMA (round 3).  The MFMA wants a lane to own 8 consecutive k of ONE row, so a
 // wave's direct global loads touch 32 different rows per instruction: 64 L1 tag look-ups for 1 KiB
-// (profiles/r02_gemm_pmc.md).  With GEMM_H2_XLDS the X tile of a wave travels HBM -> LDS by
+// (profiles/r02_gemm_pmc.md).  Since round 3 the X tile of a wave travels HBM -> LDS by
 // `global_load_lds_dwordx4` (no VGPRs, asynchronous), in chunks of 32 rows x 32 columns (2 K steps):
 // four instructions per chunk, in each of which every QUAD of lanes reads 64 contiguous bytes of
 // one row (16 look-ups per KiB: the coalesced count).  The LDS position of a lane's 16 bytes is
@@ -327,13 +327,10 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 // MFMA lane (i, h) of K step cstep reads 32 bytes at  (i>>2 & 3)·1040 + 16·(4·(4·(i>>4) + (i&3) +
 // 8·cstep) + 2·h): for the 16 lanes of a read phase the slot index mod 16 is j + 4·t + const —
 // sixteen different bank groups.
-#ifndef GEMM_H2_XLDS
-#define GEMM_H2_XLDS 1          /* 0: round 2's pipeline (X and W through VGPRs) — kept for A/B builds */
-#endif
 constexpr int kXInstrBytes = 1024 + 16;
 constexpr int kXChunkBytes = 4 * kXInstrBytes;            // 32 rows x 32 columns fp32, padded
 constexpr int kXRing = 2;                                  // chunks per wave: one in use, one in flight
-constexpr int kXLdsBytes = GEMM_H2_XLDS ? kWaves * kXRing * kXChunkBytes : 0;
+constexpr int kXLdsBytes = kWaves * kXRing * kXChunkBytes;
 
 // The two decompositions the product kernel is instantiated for (template parameter SCH):
 //   0 "h2": two fp16 parts of both operands after an exact power-of-two scaling, 3 MFMAs per product
@@ -464,15 +461,12 @@ __device__ __forceinline__ void h2_philox(uint32_t c0, uint32_t c1, uint32_t c2,
 
 // 16 bytes per lane straight from global memory into LDS (asynchronous, counted by vmcnt like a
 // load): the wave's 64 x 16 bytes land contiguously at LDS byte address `lds_addr` (wave-uniform,
-// through M0).  Issued as inline assembly ON PURPOSE (GEMM_H2_XLDS): hipcc's wait-count pass
+// through M0).  Issued as inline assembly ON PURPOSE: hipcc's wait-count pass
 // treats every LDS access after a `__builtin_amdgcn_global_load_lds` as dependent on it and drains
 // the whole prefetch with `s_waitcnt vmcnt(0)`; here the kernel places its own counted waits
 // (dma_wait<N>: N = DMA instructions issued AFTER the youngest one that must have landed — vector
 // loads complete in order, so "at most N outstanding" means everything older is in LDS; stores
 // that complete early only make the wait longer, never shorter).
-#ifndef GEMM_X_NT          /* experiment builds: 1 = the X stream (read once) is loaded non-temporally */
-#define GEMM_X_NT 0
-#endif
 __device__ __forceinline__ void dma16(const void *g, uint32_t lds_addr)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
@@ -480,12 +474,7 @@ __device__ __forceinline__ void dma16(const void *g, uint32_t lds_addr)
 }
 __device__ __forceinline__ void dma16_x(const void *g, uint32_t lds_addr)     // (the X stream)
 {
-#if GEMM_X_NT
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
-                 :: "v"(g), "s"(lds_addr) : "memory", "m0");
-#else
     dma16(g, lds_addr);
-#endif
 }
 template <int N> __device__ __forceinline__ void dma_wait()
 {
@@ -517,22 +506,6 @@ __device__ unsigned long long g_gemm_step_stamps[16];
 #define GEMM_STEP_STAMP(i) do { } while (0)
 #endif
 
-#ifdef GEMM_STAGGER
-#define GEMM_STAGGER_ON GEMM_STAGGER
-#else
-#define GEMM_STAGGER_ON 0
-#endif
-#ifdef GEMM_SPLIT_AHEAD
-#define GEMM_SPLIT_AHEAD_ON GEMM_SPLIT_AHEAD
-#else
-#define GEMM_SPLIT_AHEAD_ON 0
-#endif
-#ifdef GEMM_SPREAD_DMA
-#define GEMM_SPREAD_DMA_ON GEMM_SPREAD_DMA
-#else
-#define GEMM_SPREAD_DMA_ON 0
-#endif
-
 template <int EPI, int SCH = 0>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ x_rows,
@@ -542,7 +515,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // SCH: 0 two scaled fp16 parts (x_bound required), 1 three bf16 parts (x_bound unused) — SchemeK
     typedef SchemeK<SCH> SK;
     constexpr int NS = SK::NS, KS = SK::KS, kSchChunkBytes = SK::ChunkBytes, kSchStageBytes = SK::StageBytes;
-    static_assert(SCH == 0 || GEMM_H2_XLDS, "the three-part scheme exists in the DMA pipeline only");
     // EPI: 0 plain, 2 backward mask; forward epilogues (bias always, zeros when there is none):
     // 1 bias only, 4 + ReLU, 5 + ReLU + dropout at p = 1/2 (one-bit keep fields), 6 + ReLU + dropout
     // at any other p (16-bit fields).  Compile-time options: a uniform branch per column group in
@@ -560,24 +532,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     // indices; kChunks % kH2Ring == 0 keeps slot = step % kH2Ring valid across the boundary.
     static_assert(kChunks % kH2Ring == 0, "the X ring must divide the K steps of a tile");
     static_assert(kChunks % KS == 0 && (kChunks / KS) % 2 == 0, "W stages must alternate evenly");
-#ifndef GEMM_B3_RING3
-#define GEMM_B3_RING3 0
-#endif
-    // R3 (the three-part scheme): THREE W stage buffers, a stage issued TWO steps ahead (at the top of
-    // step c for step c + 2, into the buffer the barrier has just freed), and the X chunks issued at
-    // the BOTTOM of even steps — see the K loop.
-    constexpr bool R3 = SCH == 1 && GEMM_B3_RING3 && GEMM_H2_XLDS;
-#ifndef GEMM_STORE_IN_LOOP
-#define GEMM_STORE_IN_LOOP 0
-#endif
-    constexpr bool SIL = R3 && GEMM_STORE_IN_LOOP && EPI != 2;      // (the masked form loads in its store section)
-    static_assert(!R3 || !(GEMM_STAGGER_ON || GEMM_SPLIT_AHEAD_ON || GEMM_SPREAD_DMA_ON), "R3 excludes the other pipeline experiments");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[(R3 ? 3 : 2) * kSchStageBytes];    // the W stage buffers
-#if GEMM_H2_XLDS
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kSchStageBytes];    // the W stage buffers
     // (a separate LDS object, so the compiler's wait-count pass can tell a DMA into an X ring from
     //  a store into a W stage and does not drain the X prefetch at every W stage)
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];              // X rings, per wave
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned char *wimg = ws + kH2HeaderBytes;
     const int64_t n_tiles = (M + kTileRows - 1) / kTileRows;
@@ -622,7 +580,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         back_b = one_step ? 1.f : pow2f(back - back / 2);    // exact steps
     }
 
-#if GEMM_H2_XLDS
     static_assert(kStage == 2 && kWaves == 8, "the DMA pipeline is written for 2-step W stages and 8 waves");
     static_assert(SK::WShare % 1024 == 0, "a wave's part of a W stage is whole DMA instructions");
     const unsigned char *wl = wimg;
@@ -641,33 +598,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
             if (i < kPieces || ablate_first_tile)        //  that the stale W stages the later tiles multiply are real data)
                 dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
     };
-    [[maybe_unused]] auto w_issue_one = [&](int st, int b, int i) {           // (one of a stage's DMA instructions)
-        const unsigned char *src = wl + (size_t)st * kSchStageBytes + wave * SK::WShare + lane * 16;
-        dma16(src + i * 1024, w_lds + b * kSchStageBytes + i * 1024);
-    };
-#else
-    u32x4 wreg[kH2WLoads];
-    const unsigned char *wl = wimg;     // (re-made opaque per tile, see the tile loop)
-#endif
-    [[maybe_unused]] auto w_load = [&](int st) {
-        const u32x4 *src = (const u32x4 *)(wl + (size_t)st * kH2StageBytes);
-#if !GEMM_H2_XLDS
-#pragma unroll
-        for (int i = 0; i < kH2WLoads; ++i) wreg[i] = src[i * kThreads + tid];
-#else
-        (void)src;
-#endif
-    };
-    [[maybe_unused]] auto w_store = [&](int b) {
-#if !GEMM_H2_XLDS
-        u32x4 *dst = (u32x4 *)(lds + b * kH2StageBytes);
-#pragma unroll
-        for (int i = 0; i < kH2WLoads; ++i) dst[i * kThreads + tid] = wreg[i];
-#else
-        (void)b;
-#endif
-    };
-#if GEMM_H2_XLDS
     unsigned char *xl = xlds + __builtin_amdgcn_readfirstlane(wave) * (kXRing * kXChunkBytes);
     // (what this lane FETCHES in instruction j of a chunk, and where this MFMA lane READS)
     const int ld_row0 = 16 * ((lane >> 4) & 1) + ((lane >> 2) & 3);       // + 4·j
@@ -679,23 +609,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma16_x(src[j] + 32 * chunk, base + j * kXInstrBytes);
     };
-    [[maybe_unused]] auto x_issue_one = [&](const float *const (&src)[4], int chunk, int slot, int j) {
-        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)xl + slot * kXChunkBytes;
-        dma16_x(src[j] + 32 * chunk, base + j * kXInstrBytes);
-    };
     auto a_read = [&](int cstep, int slot, f32x4 &lo, f32x4 &hi) {
         const unsigned char *q = xl + slot * kXChunkBytes + rd_off + 512 * cstep;
         lo = *(const f32x4 *)q;
         hi = *(const f32x4 *)(q + 16);
     };
-#else
-    f32x4 ar[kH2Ring][2];      // X fragments: this step + (kH2Ring - 1) steps of prefetch
-    auto a_fetch = [&](const float *xr, int c, f32x4 &lo, f32x4 &hi) {
-        const f32x4 *p = (const f32x4 *)(xr + c * kChunk);
-        lo = p[0];
-        hi = p[1];
-    };
-#endif
     u32x4 Ah, Am;
     [[maybe_unused]] u32x4 Al;                     // (third part: SCH 1 only)
     auto split_frag = [&](const f32x4 &lo, const f32x4 &hi, bool ok) {
@@ -733,14 +651,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         src = ok ? (x_rows ? (int64_t)x_rows[row] : row) : 0;
     };
 
-    [[maybe_unused]] int wbuf = 0;              // R3: the buffer (0..2) of the current step's W stage
-    [[maybe_unused]] bool stored_prev = false;  // R3: the previous tile's store section issued its 32 stores
     int64_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     int64_t row, src_row;
     bool row_ok;
     tile_rows(tile, row, row_ok, src_row);
-#if GEMM_H2_XLDS
     // the four rows this lane fetches per chunk (one per DMA instruction), as row pointers
     auto load_rows = [&](int64_t t, const float *(&src)[4]) {
 #pragma unroll
@@ -756,34 +671,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
     x_issue(xsrc, 0, 0);
     w_issue(0, 0);
     x_issue(xsrc, 1, 1);
-    if constexpr (R3) {
-        w_issue(1, 1);
-        dma_wait<7>();             // X chunk 0 and W stage 0 landed; X chunk 1 and W stage 1 may still fly
-    } else {
-        dma_wait<4>();             // X chunk 0 and this wave's part of W stage 0 are in LDS
-    }
-#ifndef GEMM_STAGGER
-#define GEMM_STAGGER 0
-#endif
-    // STAGGER (MI355X_MICROARCH.md, "two waves that run the same program with one barrier per
-    // block"): waves w and w + 4 share a SIMD and, left alone, run in lockstep — both multiply, then
-    // both split the next step's X fragment (VALU) while the matrix pipe idles.  With the stagger
-    // waves 4-7 split a step's fragment at the TOP of the step (under the partner's MFMA run) and
-    // waves 0-3 at the bottom (under the partner's last MFMAs): same arithmetic, same results.
-    const bool late = GEMM_STAGGER && __builtin_amdgcn_readfirstlane(wave) >= 4;
-    if (!late) {
+    dma_wait<4>();                 // X chunk 0 and this wave's part of W stage 0 are in LDS
+    {
         f32x4 lo, hi;
         a_read(0, 0, lo, hi);
         split_frag(lo, hi, row_ok);
     }
-#else
-    const float *xrow = X + src_row * ldx + 8 * (lane >> 5);
-    w_load(0);
-#pragma unroll
-    for (int c = 0; c < kH2Ring - 1; ++c) a_fetch(xrow, c, ar[c][0], ar[c][1]);
-    w_store(0);
-    split_frag(ar[0][0], ar[0][1], row_ok);
-#endif
     uint32_t vmax = 0u;   // max of |y| as BITS: unsigned order = float order for finite values, and
                           // inf / NaN patterns sort above every finite one (an overflow is never lost)
 
@@ -803,12 +696,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         int64_t row_n, src_n;
         bool ok_n;
         tile_rows(tile + gridDim.x, row_n, ok_n, src_n);
-#if GEMM_H2_XLDS
         const float *xsrc_n[4];
         load_rows(tile + gridDim.x, xsrc_n);
-#else
-        const float *xrow_n = X + src_n * ldx + 8 * (lane >> 5);
-#endif
         // (masked form: the row of the mask this lane will read in the store section — looked up
         //  here, a whole K loop ahead of its use)
         int64_t mask_row = src_row;
@@ -819,12 +708,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
         // ---- the store section of a tile, as two pieces: what is computed once per tile, and one
-        // column block's scaling / epilogue / four 16-byte stores.  They run after the K loop — or,
-        // with SIL (stores in the loop), column block by column block INSIDE the tile's last K step,
-        // right after the block's final MFMA: a store instruction costs the issuing wave ~50 cycles
-        // of address-unit time whatever it carries, 32 of them per wave at one point of the tile
-        // leave the matrix pipe idle for 12 000 cycles; spread under the last step's MFMA run they
-        // overlap it.
+        // column block's scaling / epilogue / four 16-byte stores.  They run after the K loop: 32
+        // store instructions per wave at one point of the tile, the matrix pipe idle for 12 000 cycles
+        // (gemm_xw256_s16_kernel hides them under the next tile; measured and dropped here: the
+        // blocks inside the tile's last K step — DESIGN §7).
         float *yrow = nullptr;
         const float *mrow = nullptr;
         uint32_t r1[4] = {0u, 0u, 0u, 0u};
@@ -920,11 +807,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
 #ifdef GEMM_H2_ABLATE_STORES      /* ablation build only: keeps the arithmetic, drops the traffic */
                     if (v.x == 1.2345e-30f)
 #endif
-#if defined(GEMM_STORE_NT) && GEMM_STORE_NT      /* experiment builds: Y (written once) stored non-temporally */
-                    __builtin_nontemporal_store(v, (f32x4 *)(yrow + 32 * nb + 8 * g));
-#else
                     *(f32x4 *)(yrow + 32 * nb + 8 * g) = v;
-#endif
                     if (y_absmax != nullptr) {                                 // (wave-uniform)
                         if (RELU)                    // stored values are >= 0 (or NaN): the bits as they are
                             vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
@@ -939,50 +822,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 if (DROP16) __builtin_amdgcn_sched_barrier(0);
             
         };
-        if (SIL && row_ok) store_prelude();
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             const int st = c / KS;
             GEMM_STEP_STAMP(0);
-#if GEMM_H2_XLDS
             if (c % KS == 0) {
                 // every wave waited for ITS part of W stage st before it got here (end of the
                 // previous stage / prologue) and has read its last fragment of stage st - 1
                 __builtin_amdgcn_s_barrier();
                 GEMM_STEP_STAMP(1);
-#ifndef GEMM_SPREAD_DMA
-#define GEMM_SPREAD_DMA 0
-#endif
-                if constexpr (R3) {
-                    // the barrier has freed the buffer of stage c - 1 = (wbuf + 2) % 3: stage c + 2 goes
-                    // there now — two steps of flight (stages of the next tile are the same image)
-                    if (c + 2 < kChunks || has_next) {
-                        const int b2 = wbuf == 0 ? 2 : wbuf - 1;
-                        w_issue((c + 2) % kChunks, b2);
-                    }
-                } else
-                // (SPREAD_DMA: the stage's DMA instructions are issued one by one between this step's
-                //  MFMA groups instead of as a burst behind the barrier — 8 waves x 3-7 instructions at
-                //  one point of time queue up in front of the CU's one address unit, and a wave that
-                //  cannot issue its DMA cannot issue its first MFMA either)
-                if (!GEMM_SPREAD_DMA) {
-                    if ((st + 1) * KS < kChunks)
-                        w_issue(st + 1, (st + 1) & 1);
-                    else if (has_next)
-                        w_issue(0, 0);                                // the next tile's first stage
-                }
-            }
-#else
-            if (c % kStage == 0) {
-                __syncthreads();
-                if ((st + 1) * kStage < kChunks)
-                    w_load(st + 1);
+                if ((st + 1) * KS < kChunks)
+                    w_issue(st + 1, (st + 1) & 1);
                 else if (has_next)
-                    w_load(0);                                    // the next tile's first stage
+                    w_issue(0, 0);                                // the next tile's first stage
             }
-#endif
-#if GEMM_H2_XLDS
-            if (!R3 && !GEMM_SPREAD_DMA && (c & 1)) {
+            if (c & 1) {
                 // chunk m = (c + 3) / 2 goes into the ring slot chunk m - 2 has just left (its last
                 // fragment was read at the end of step c - 1): three K steps of flight time
                 constexpr int kCh = kChunks / 2;
@@ -992,49 +846,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 else if (has_next)
                     x_issue(xsrc_n, m - kCh, m & 1);
             }
-#else
-            {
-                constexpr int R = kH2Ring;
-                const int fc = c + R - 1;                         // step fetched now
-                if (fc < kChunks)
-                    a_fetch(xrow, fc, ar[fc % R][0], ar[fc % R][1]);
-                else if (has_next)
-                    a_fetch(xrow_n, fc - kChunks, ar[fc % R][0], ar[fc % R][1]);
-            }
-#endif
-#ifndef GEMM_SPLIT_AHEAD
-#define GEMM_SPLIT_AHEAD 0
-#endif
             GEMM_STEP_STAMP(2);
-#if GEMM_H2_XLDS
-            if (late) {
-                f32x4 lo, hi;
-                a_read(c & 1, (c >> 1) & 1, lo, hi);
-                split_frag(lo, hi, row_ok);
-                if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
-                else asm volatile("" : "+v"(Ah), "+v"(Am));
-            }
-#endif
-            // SPLIT AHEAD: the NEXT step's X fragment is already in LDS at the top of this step (b3:
-            // the wait that ends every step; h2: an extra counted wait at the end of even steps,
-            // below), so it is read here and split into its parts in four pieces BETWEEN this
-            // step's MFMA groups — VALU work that issues in the shadow of the wave's own MFMAs
-            // (the matrix pipe holds the vector issue for 8 of an MFMA's 32 cycles) instead of as
-            // one block between the last MFMA and the barrier, where the pipe idles.
-            [[maybe_unused]] f32x4 nlo, nhi;
-            [[maybe_unused]] uint32_t nh[4], nm[4], nl[4];
-            [[maybe_unused]] const bool have_next = GEMM_SPLIT_AHEAD && (c + 1 < kChunks || has_next);
-            [[maybe_unused]] const bool n_ok = c + 1 < kChunks ? row_ok : ok_n;
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-            if (have_next) {
-                const int cn = (c + 1) % kChunks;
-                a_read(cn & 1, (cn >> 1) & 1, nlo, nhi);
-            }
-#endif
             const u32x4 Xh = Ah, Xm = Am;
             [[maybe_unused]] const u32x4 Xl = Al;
-            const unsigned char *buf = R3 ? lds + wbuf * kSchStageBytes
-                                          : lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
+            const unsigned char *buf = lds + (st & 1) * kSchStageBytes + (c % KS) * kSchChunkBytes;
             u32x4 Bf[2][NS];
             auto b_read = [&](int nb, u32x4 (&dst)[NS]) {
 #pragma unroll
@@ -1046,31 +861,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 if (nb + 1 < 8) b_read(nb + 1, Bf[(nb + 1) & 1]);
                 const u32x4 Bh = Bf[nb & 1][0], Bm = Bf[nb & 1][1];
                 f32x16 t = acc[nb];
-#ifndef GEMM_NO_SETPRIO    /* experiment builds */
-#define GEMM_NO_SETPRIO 0
-#endif
-                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#ifdef GEMM_MFMA16_HACK   /* THROUGHPUT PROBE ONLY — results are garbage: every 32x32x16 MFMA replaced by two
-                             16x16x32 MFMAs (same flops, same cycles) on the same operand registers, to see
-                             which clock the chip holds on the other shape inside THIS kernel (guide rule 28) */
-                if constexpr (SCH == 1) {
-                    typedef float f32x4v __attribute__((ext_vector_type(4)));
-                    const u32x4 Bl = Bf[nb & 1][NS - 1];
-                    f32x4v q0 = {t[0], t[1], t[2], t[3]}, q1 = {t[4], t[5], t[6], t[7]};
-                    f32x4v q2 = {t[8], t[9], t[10], t[11]}, q3 = {t[12], t[13], t[14], t[15]};
-                    auto m16 = [&](u32x4 a, u32x4 b, f32x4v c) {
-                        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-                    };
-                    // (twelve DISTINCT (A, B, accumulator) triples: identical ones would be merged by the compiler)
-                    q0 = m16(Bh, Xl, q0); q1 = m16(Bl, Xl, q1);
-                    q2 = m16(Bl, Xh, q2); q3 = m16(Bm, Xl, q3);
-                    q0 = m16(Bm, Xm, q0); q1 = m16(Bl, Xm, q1);
-                    q2 = m16(Bh, Xm, q2); q3 = m16(Bm, Xm, q3);
-                    q0 = m16(Bm, Xh, q0); q1 = m16(Bl, Xh, q1);
-                    q2 = m16(Bh, Xh, q2); q3 = m16(Bh, Xl, q3);
-                    t = f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
-                } else
-#endif
+                __builtin_amdgcn_s_setprio(1);
                 if constexpr (SCH == 1) {
                     // (the order of gemm_xw256_kernel, smallest terms first: results are bit-identical)
                     const u32x4 Bl = Bf[nb & 1][NS - 1];
@@ -1085,95 +876,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     t = mfma_h(Bh, Xm, t);
                     t = mfma_h(Bh, Xh, t);
                 }
-                if (!GEMM_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 acc[nb] = t;
-                if constexpr (SIL) {
-                    if (c == kChunks - 1 && row_ok) store_block(nb);
-                }
                 if (nb == 0) GEMM_STEP_STAMP(3);
                 if (nb == 3) GEMM_STEP_STAMP(4);
                 if (nb == 7) GEMM_STEP_STAMP(5);
-#if GEMM_H2_XLDS && GEMM_SPREAD_DMA
-                {
-                    // issue order as in the burst form (the counted waits depend on it): the stage's W
-                    // instructions first (on the step that opens a stage), then the X chunk's four (odd steps)
-                    constexpr int kWI = SK::WShare / 1024;
-                    const bool w_step = c % KS == 0;
-                    const int wi = w_step ? nb : -1;
-                    const int xi = (c & 1) ? nb - (w_step ? kWI : 0) : -1;
-                    if (wi >= 0 && wi < kWI) {
-                        if ((st + 1) * KS < kChunks)
-                            w_issue_one(st + 1, (st + 1) & 1, wi);
-                        else if (has_next)
-                            w_issue_one(0, 0, wi);
-                    }
-                    if (xi >= 0 && xi < 4) {
-                        constexpr int kCh = kChunks / 2;
-                        const int m = (c + 3) / 2;
-                        if (m < kCh)
-                            x_issue_one(xsrc, m, m & 1, xi);
-                        else if (has_next)
-                            x_issue_one(xsrc_n, m - kCh, m & 1, xi);
-                    }
-                }
-#endif
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-                if (have_next && (nb & 1)) {            // one pair of the next fragment per two column blocks
-                    const int j = nb >> 1;
-                    const float a0 = j == 0 ? nlo.x : (j == 1 ? nlo.z : (j == 2 ? nhi.x : nhi.z));
-                    const float a1 = j == 0 ? nlo.y : (j == 1 ? nlo.w : (j == 2 ? nhi.y : nhi.w));
-                    if constexpr (SCH == 1) {
-                        split3_pair(n_ok ? a0 : 0.f, n_ok ? a1 : 0.f, nh[j], nm[j], nl[j]);
-                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]), "+v"(nl[j]));
-                    } else {
-                        const float x0 = n_ok ? a0 * xs : 0.f, x1 = n_ok ? a1 * xs : 0.f;
-                        f32x2 v = {x0, x1};
-                        const h16x2 hh = __builtin_convertvector(v, h16x2);
-                        const f32x2 hb = __builtin_convertvector(hh, f32x2);
-                        f32x2 r = {x0 - hb.x, x1 - hb.y};
-                        const h16x2 mm = __builtin_convertvector(r, h16x2);
-                        nh[j] = __builtin_bit_cast(uint32_t, hh);
-                        nm[j] = __builtin_bit_cast(uint32_t, mm);
-                        asm volatile("" : "+v"(nh[j]), "+v"(nm[j]));
-                    }
-                }
-#endif
             }
-#if GEMM_H2_XLDS && GEMM_SPLIT_AHEAD
-            if (have_next) {
-                Ah = u32x4{nh[0], nh[1], nh[2], nh[3]};
-                Am = u32x4{nm[0], nm[1], nm[2], nm[3]};
-                if constexpr (SCH == 1) Al = u32x4{nl[0], nl[1], nl[2], nl[3]};
-            }
-            if (SCH == 0 && (c & 1) == 0 && (c + 2 < kChunks || has_next))
-                dma_wait<4>();      // (h2: the X chunk of step c + 2 has landed; only this step's W stage may still fly)
-#endif
-#if GEMM_H2_XLDS
-            if constexpr (R3) {
-                // Before the next step: this wave's part of W stage c + 1 (issued at the top of step
-                // c - 1) and the X fragment of step c + 1 must be in LDS.  Issued AFTER that stage, in
-                // order: the X chunk of the bottom of step c - 1 (c odd: 4), the previous tile's 32
-                // stores (c == 0), the stage issued at the top of this step (3) — all of them may
-                // still be in flight: vector-memory operations retire in order on one counter.
-                constexpr int kCh = kChunks / 2;
-                if (c + 1 < kChunks || has_next) {
-                    const bool w_top = (c + 2 < kChunks) || has_next;
-                    const bool x_prev = (c & 1) && (((c + 3) / 2 < kCh) || has_next);
-                    const bool st_prev = c == 0 && stored_prev;
-                    // (SIL: this tile's stores were issued DURING step 15, after everything step 16
-                    //  = the next tile's step 0 needs: they may all still be in flight at its bottom)
-                    const bool st_now = SIL && c == kChunks - 1 && __builtin_amdgcn_ballot_w64(row_ok) != 0ull;
-                    if (st_now) {                            // (c == 15 with a next tile: x_prev and w_top hold)
-                        dma_wait<39>();
-                    } else if (st_prev) {                    // (c == 0: x_prev is false)
-                        if (w_top) dma_wait<35>(); else dma_wait<32>();
-                    } else if (x_prev) {
-                        if (w_top) dma_wait<7>(); else dma_wait<4>();
-                    } else {
-                        if (w_top) dma_wait<3>(); else dma_wait<0>();
-                    }
-                }
-            } else
             if (c % KS == KS - 1) {
                 // before the next stage: this wave's part of W stage st + 1 and the X chunk of the
                 // next K step must be in LDS.  Younger than both: only the 4 DMA instructions of an
@@ -1187,21 +895,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                     else dma_wait<0>();
                 }
             }
-#else
-            if (c % kStage == kStage - 1) {
-                if (c + 1 < kChunks)
-                    w_store((st + 1) & 1);
-                else if (has_next)
-                    w_store(0);              // (stage kChunks/kStage would use buffer 0 too)
-            }
-#endif
-#if GEMM_H2_XLDS
             GEMM_STEP_STAMP(6);
 #ifdef GEMM_PROFILE_STAMPS
             if (c == 1) { unsigned long long t2; GEMM_STAMP(t2); st_f2 += t2 - st_a; }
             if (c == 7) { unsigned long long t8; GEMM_STAMP(t8); st_f8 += t8 - st_a; }
 #endif
-            if (!GEMM_SPLIT_AHEAD && !late && (c + 1 < kChunks || has_next)) {
+            if (c + 1 < kChunks || has_next) {
                 const int cn = (c + 1) % kChunks;                 // (chunk slots alternate: 8 chunks per tile)
                 f32x4 lo, hi;
                 a_read(cn & 1, (cn >> 1) & 1, lo, hi);
@@ -1209,45 +908,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
                 if constexpr (SCH == 1) asm volatile("" : "+v"(Ah), "+v"(Am), "+v"(Al));
                 else asm volatile("" : "+v"(Ah), "+v"(Am));
             }
-#else
-            if (c + 1 < kChunks) {
-                split_frag(ar[(c + 1) % kH2Ring][0], ar[(c + 1) % kH2Ring][1], row_ok);
-                asm volatile("" : "+v"(Ah), "+v"(Am));
-            } else if (has_next) {
-                split_frag(ar[0][0], ar[0][1], ok_n);
-                asm volatile("" : "+v"(Ah), "+v"(Am));
-            }
-#endif
-#if GEMM_H2_XLDS
-            if constexpr (R3) {
-                if ((c & 1) == 0) {
-                    // chunk m = (c + 4) / 2 goes into the ring slot whose chunk m - 2 has just given up
-                    // its last fragment (the read above): issued HERE, at the bottom of the step, where
-                    // a wave that has to queue behind the address unit waits beside its SIMD partner's
-                    // MFMA run instead of in front of its own
-                    constexpr int kCh = kChunks / 2;
-                    const int m = (c + 4) / 2;
-                    if (m < kCh)
-                        x_issue(xsrc, m, m & 1);
-                    else if (has_next)
-                        x_issue(xsrc_n, m - kCh, m & 1);
-                }
-                wbuf = wbuf == 2 ? 0 : wbuf + 1;
-            }
-#endif
             GEMM_STEP_STAMP(7);
         }
 
         GEMM_STAMP(st_b);
-        if (!SIL && row_ok) {
+        if (row_ok) {
             store_prelude();
 #pragma unroll
             for (int nb = 0; nb < 8; ++nb) store_block(nb);
         }
-        // (R3's first wait of the next tile counts this tile's stores: exactly 32 per wave when any
-        //  lane stored — the masked instantiation also LOADS in its store section: not counted there,
-        //  its first wait then simply covers them)
-        stored_prev = !MASKED && __builtin_amdgcn_ballot_w64(row_ok) != 0ull;
         GEMM_STAMP(st_c);
 #ifdef GEMM_PROFILE_STAMPS
         st_k += st_b - st_a;
@@ -1257,12 +926,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_h2_kernel(
         row = row_n;
         row_ok = ok_n;
         src_row = src_n;
-#if GEMM_H2_XLDS
 #pragma unroll
         for (int j = 0; j < 4; ++j) xsrc[j] = xsrc_n[j];
-#else
-        xrow = xrow_n;
-#endif
     }
     if (y_absmax != nullptr) {                 // |y| >= 0: float order == unsigned order of the bits
 #pragma unroll
@@ -2628,7 +2293,7 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
                            (uint16_t *)((unsigned char *)workspace + kH2HeaderBytes));
     const int64_t tiles = s16 ? (M + kS16Rows - 1) / kS16Rows : (M + kTileRows - 1) / kTileRows;
     // dynamic LDS of the X-through-LDS build: the two W stages + every wave's X ring (> 64 KiB)
-    const size_t dyn = s16 ? (size_t)kS16LdsBytes : (GEMM_H2_XLDS ? (size_t)kXLdsBytes : 0);
+    const size_t dyn = s16 ? (size_t)kS16LdsBytes : (size_t)kXLdsBytes;
     if (dyn) {
         static bool raised = false;          // (idempotent; a benign race sets it twice)
         if (!raised) {
