@@ -1,17 +1,24 @@
 // gcn_gemm.hip — the dense half of GraphConvolution on gfx950 MFMA:
 // `support = torch.mm(input, self.weight)` (reference pygcn/layers.py:33) and the two GEMMs of its
-// backward, at the layer shapes of configs C3–C5.  Five kernels:
+// backward, at the layer shapes of configs C3–C5.  Six kernels:
 //
-//   gemm_xw256_h2_kernel   Y[M,256] = X[M,256]·W[256,256], fp32 in / out (the default).  gfx950 has
-//                          no reduced-precision fp32 MFMA and the exact one runs at 1/16 of the
-//                          16-bit rate, so both operands are scaled by exact powers of two and
-//                          split into TWO fp16 parts: x·w ≈ h·h' + h·m' + m·h', three MFMAs per
-//                          product, ~4e-7 normwise against fp64.  Optional row list on the input,
-//                          the layer's forward epilogue (bias, ReLU, Philox dropout) or the
-//                          ReLU/dropout backward mask in the store, max|Y| as a side result.
-//   gemm_xw256_kernel      the same product from three bf16 parts (six MFMAs, no scaling) — round
-//                          1's kernel, kept as the scheme that needs no bound of max|X|.
-//   gemm_atg256_h2_kernel  grad_W[256,256] = Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] over a row LIST (+ ordered
+//   gemm_xw256_h2_kernel<EPI, SCH>   Y[M,256] = X[M,256]·W[256,256], fp32 in / out.  gfx950 has no
+//                          reduced-precision fp32 MFMA and the exact one runs at 1/16 of the 16-bit
+//                          rate, so the operands are split into 16-bit parts.  SCH 1 (the DEFAULT
+//                          since round 4, fp32-EQUIVALENT): three bf16 parts, six MFMAs per product,
+//                          a 24-bit significand, no scaling; SCH 0 (opt-in): both operands scaled
+//                          by exact powers of two and split into TWO fp16 parts, x·w ≈ h·h' + h·m' +
+//                          m·h', three MFMAs, 22 bits.  Optional row list on the input, the layer's
+//                          forward epilogue (bias, ReLU, Philox dropout) or the ReLU / dropout
+//                          backward mask in the store, max|Y| as a side result.  Round 3's pipeline:
+//                          256-row tiles, X and W by HBM -> LDS DMA, persistent workgroups.
+//   gemm_xw256_s16_kernel<EPI>       the three-part product on CONTIGUOUS rows (round 4): 128-row
+//                          tiles on 16x16x32 MFMAs, the previous tile's stores, the DMA and the
+//                          operand split between the running tile's MFMA groups — what the default
+//                          scheme runs wherever no row list is given (6.2 ms against 7.05 at M = 10^7).
+//   gemm_xw256_kernel      the three-part product in round 1's form (VGPR-staged), kept as the
+//                          bit-exact reference of SCH 1.
+//   gemm_atg256_h2_kernel<SCH>  grad_W[256,256] = Σ_r A[ra[r]]ᵀ ⊗ G[rg[r]] over a row LIST (+ ordered
 //                          slab reduction), the weight gradient without compacting copies.
 //   gemm_bf16_kernel<K,N>  bf16 storage (config C5: 128 -> 128), W resident in LDS, streaming.
 //   gemm_atg128_bf16_kernel the weight gradient at bf16 storage (128 x 128).
@@ -34,9 +41,10 @@
 // opaque asm, or hipcc sinks it back to just after the barrier, where it idles the pipe).  W is
 // split and fragment-ordered once per call by a small prep kernel into the workspace.
 //
-// Measured on MI355X at M = 10^7 (one process, interleaved): h2 4.8 ms plain / 5.1 ms with the layer
-// epilogue (persistent workgroups, X and W by HBM -> LDS DMA, cross-tile pipeline; round 2: 5.2 /
-// 6.9), three bf16 parts 7.5 ms, hipBLASLt fp32 9.95 ms.  The h2 kernel is
+// Measured on MI355X at M = 10^7 (one process, interleaved): three bf16 parts 6.2 ms plain / 6.45 with
+// the layer epilogue (gemm_xw256_s16_kernel; round 3's pipeline 7.05, round 1's kernel 7.5), h2 4.8 /
+// 4.9 ms (round 2: 5.2 / 6.9), hipBLASLt fp32 9.95 ms.  The three-part kernels are power-managed (same
+// cycles per tile with and without their memory streams; the chip holds 1.57 GHz), the h2 kernel is
 // bound by the CU's vector-memory instruction issue (3e7 wave-level loads / stores of 1 KiB per
 // launch, already 16 B per lane), not by MFMA (48 % busy) or HBM (4.3 TB/s): DESIGN §3.7, with the
 // variants that were measured and rejected in §7 (resident-W column split, stores through LDS,
