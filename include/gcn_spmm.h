@@ -36,7 +36,7 @@ extern "C" {
 #define GCN_DTYPE_F32  0      /* B, C fp32; fp32 accumulate  (configs C1-C4)                  */
 #define GCN_DTYPE_BF16 1      /* B, C bf16 storage; fp32 values and accumulate (config C5)    */
 
-#define GCN_ABI_VERSION 24
+#define GCN_ABI_VERSION 25
 
 #define GCN_DEFAULT_ITEM_COST   64     /* work units (stored entries + rows) per row-batch item */
 #define GCN_DEFAULT_LONG_THRESH 256    /* rows with more stored entries are chunked             */
@@ -477,6 +477,14 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
 int gcn_gemm_atg256_f32_b3(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
                            const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* ... and (ABI 25) with the BIAS gradient of the same layer as a side result: colsum_g[256] (DEVICE
+ * floats) = Σ_{r < n_list} G[rows_g[r], :] — `grad_output.sum(0)` of `output + self.bias`
+ * (pygcn/layers.py:36) over the rows on which the gradient can be non-zero — summed from the rows the
+ * kernel loads anyway (8 rows at a time, compensated running sums, workgroup partials added in
+ * order in double precision: deterministic), instead of in a pass of its own over G. */
+int gcn_gemm_atg256_f32_b3_colsum(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                                  const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, float *colsum_g,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * The same weight gradient for bf16 STORAGE (config C5: 128 -> 128 layers): A [*, K] and G [*, N]

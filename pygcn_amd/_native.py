@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (GCN_SPMM_LIB: an experiment build of the same ABI — tools/*_variant_sweep.py; never set in product use)
 LIB_PATH = os.environ.get("GCN_SPMM_LIB") or os.path.join(_HERE, "csrc", "libgcn_spmm.so")
 
-GCN_ABI_VERSION = 24
+GCN_ABI_VERSION = 25
 GCN_REDUCE_SUM = 0
 GCN_REDUCE_MAX = 1
 GCN_DEFAULT_ITEM_COST = 64
@@ -73,7 +73,7 @@ EXPORTS = ("gcn_abi_version", "gcn_last_error", "gcn_plan_count_host", "gcn_plan
            "gcn_nll_log_softmax_backward_colsum", "gcn_gemm_atg_bf16_workspace_bytes",
            "gcn_gemm_atg_bf16", "gcn_sddmm_csr", "gcn_rows_pack_count", "gcn_rows_pack_values",
            "gcn_rows_unpack", "gcn_bits_row_counts", "gcn_gemm_xw256_b3_workspace_bytes",
-           "gcn_gemm_xw256_f32_b3", "gcn_gemm_atg256_f32_b3")
+           "gcn_gemm_xw256_f32_b3", "gcn_gemm_atg256_f32_b3", "gcn_gemm_atg256_f32_b3_colsum")
 
 _lib = None
 
@@ -199,6 +199,11 @@ def lib():
     L.gcn_gemm_atg256_f32_b3.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.gcn_gemm_atg256_f32_b3_colsum.restype = ctypes.c_int
+    L.gcn_gemm_atg256_f32_b3_colsum.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_void_p]
     L.gcn_gemm_bf16_workspace_bytes.restype = ctypes.c_size_t
     L.gcn_gemm_bf16_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int64]
     L.gcn_gemm_xw_bf16.restype = ctypes.c_int

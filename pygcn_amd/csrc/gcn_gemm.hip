@@ -1692,8 +1692,10 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
     const float *__restrict__ A, int64_t lda, const int32_t *__restrict__ ra,
     const float *__restrict__ G, int64_t ldg, const int32_t *__restrict__ rg, int64_t n_list,
     const float *__restrict__ a_bound, const float *__restrict__ g_bound,
-    float *__restrict__ partial, int64_t supers_per_wg)
+    float *__restrict__ partial, int64_t supers_per_wg, float *__restrict__ cs_partial)
 {
+    // cs_partial (three-part ring form only, else NULL): [workgroups][256] column sums of the listed G rows —
+    // the bias gradient of the layer whose weight gradient this is, from the rows the kernel loads anyway
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // 2 buffers of kAtgBufBytes
     const int tid = threadIdx.x, lane = tid & 63;
     [[maybe_unused]] unsigned long long st_begin = 0;
@@ -1825,11 +1827,24 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = *(const f32x4 *)(src + (int64_t)idx[j] * ld);
         };
+        // (column sums of G: lane l of a G wave holds columns 4l .. 4l + 3 of every row it loads; the 8 rows
+        //  of a publish are summed first, then added to the running sum with a compensation term)
+        const bool do_cs = cs_partial != nullptr && op == 1;                              // (uniform)
+        float cs_sum[4] = {0.f, 0.f, 0.f, 0.f}, cs_comp[4] = {0.f, 0.f, 0.f, 0.f}, cs_loc[4] = {0.f, 0.f, 0.f, 0.f};
         auto pair_of = [&](int q, int j, int64_t k0, int64_t end, uint32_t &h_, uint32_t &m_, uint32_t &l_) __attribute__((always_inline)) {
             const bool l0 = k0 + 2 * j < end, l1 = k0 + 2 * j + 1 < end;                  // (uniform)
             const float a = q == 0 ? v[2 * j].x : (q == 1 ? v[2 * j].y : (q == 2 ? v[2 * j].z : v[2 * j].w));
             const float c = q == 0 ? v[2 * j + 1].x : (q == 1 ? v[2 * j + 1].y : (q == 2 ? v[2 * j + 1].z : v[2 * j + 1].w));
-            split3_pair(l0 ? a : 0.f, l1 ? c : 0.f, h_, m_, l_);
+            const float am = l0 ? a : 0.f, cm = l1 ? c : 0.f;
+            split3_pair(am, cm, h_, m_, l_);
+            if (do_cs) {
+                cs_loc[q] = j == 0 ? am + cm : cs_loc[q] + (am + cm);
+                if (j == 3) {
+                    const float y = cs_loc[q] - cs_comp[q], t = cs_sum[q] + y;
+                    cs_comp[q] = (t - cs_sum[q]) - y;
+                    cs_sum[q] = t;
+                }
+            }
         };
         // where this wave's fragments of a step buffer go: tile 2q + (lane >> 5) at + 2 q NS fragments
         const int mine_off = (int)(((size_t)(op * 8 + (lane >> 5)) * NS) * kFragBytes) + ((lane & 31) + 32 * kh) * 16;
@@ -1922,6 +1937,13 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
                 e = e2; o = o2; p = p2;
             }
         }
+        if (cs_partial != nullptr) {                            // (uniform; the ring is free: the loop ends with a barrier)
+            float *red = (float *)lds;                          // [G wave 4][256]
+            if (op == 1) *(f32x4 *)(red + w8 * 256 + 4 * lane) = f32x4{cs_sum[0], cs_sum[1], cs_sum[2], cs_sum[3]};
+            __syncthreads();
+            if (tid < 256)
+                cs_partial[(size_t)blockIdx.x * 256 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+        }
     } else
     if (s0 < s1) {                                               // (uniform over the workgroup)
 #pragma unroll
@@ -2007,6 +2029,14 @@ __global__ __launch_bounds__(512, 2) void gemm_atg256_h2_kernel(
                 out[row * kN + col] = SCH == 0 ? acc[ib][jb][reg] * back_a * back_b : acc[ib][jb][reg];
             }
         }
+}
+
+__global__ __launch_bounds__(256) void atg_colsum_reduce_kernel(const float *__restrict__ cs_partial, int n_wg,
+                                                                float *__restrict__ colsum)
+{
+    double s = 0.0;                                          // (workgroup order: deterministic)
+    for (int w = 0; w < n_wg; ++w) s += (double)cs_partial[(size_t)w * 256 + threadIdx.x];
+    colsum[threadIdx.x] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void atg_reduce_kernel(const float *__restrict__ partial, int n_wg,
@@ -2478,22 +2508,25 @@ static int64_t atg_wgs(int64_t n_list)
 size_t gcn_gemm_atg256_workspace_bytes(int64_t n_list)
 {
     if (n_list <= 0) return 256;
-    return (size_t)atg_wgs(n_list) * (size_t)(kK * kN) * sizeof(float);
+    return (size_t)atg_wgs(n_list) * (size_t)(kK * kN + kN) * sizeof(float);      // partial products + column sums
 }
 
 }   // extern "C"
 
 static int atg256_launch(int sch, const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
                          const int32_t *rows_g, int64_t n_list, const float *a_absmax_bound,
-                         const float *g_absmax_bound, float *out, int64_t ldo, void *workspace,
+                         const float *g_absmax_bound, float *out, int64_t ldo, float *colsum_g, void *workspace,
                          size_t workspace_bytes, void *stream)
 {
     if (n_list < 0 || lda < kK || ldg < kN || ldo < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: bad sizes");
     if (out == nullptr) return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: NULL output");
+    if (colsum_g != nullptr && !(sch == 1 && ATG_B3_STEP16))
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32: column sums exist in the three-part form only");
     hipStream_t s = (hipStream_t)stream;
     if (n_list == 0) {
         hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)kN * 4, kK, s);
+        if (e == hipSuccess && colsum_g != nullptr) e = hipMemsetAsync(colsum_g, 0, (size_t)kN * 4, s);
         return e == hipSuccess ? 0 : gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32: memset");
     }
     if (A == nullptr || G == nullptr || rows_a == nullptr || rows_g == nullptr || workspace == nullptr ||
@@ -2506,6 +2539,7 @@ static int atg256_launch(int sch, const float *A, int64_t lda, const int32_t *ro
     const int64_t n_wg = atg_wgs(n_list);
     const int64_t supers = (n_list + 31) / 32;
     const int64_t per = (supers + n_wg - 1) / n_wg;
+    float *cs_partial = (float *)workspace + (size_t)n_wg * (kK * kN);
     {
         static bool lds_set = false;
         if (!lds_set) {
@@ -2520,12 +2554,17 @@ static int atg256_launch(int sch, const float *A, int64_t lda, const int32_t *ro
     }
     if (sch == 0)
         hipLaunchKernelGGL(gemm_atg256_h2_kernel<0>, dim3((unsigned)n_wg), dim3(512), atg_lds_bytes<0>(), s, A, lda,
-                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
+                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per,
+                           (float *)nullptr);
     else
         hipLaunchKernelGGL(gemm_atg256_h2_kernel<1>, dim3((unsigned)n_wg), dim3(512), atg_lds_bytes<1>(), s, A, lda,
-                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per);
+                           rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, (float *)workspace, per,
+                           colsum_g != nullptr ? cs_partial : (float *)nullptr);
     hipLaunchKernelGGL(atg_reduce_kernel, dim3(kK * kN / 256), dim3(256), 0, s, (const float *)workspace,
                        (int)n_wg, out, ldo);
+    if (colsum_g != nullptr)
+        hipLaunchKernelGGL(atg_colsum_reduce_kernel, dim3(1), dim3(256), 0, s, (const float *)cs_partial, (int)n_wg,
+                           colsum_g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return gcn_internal_fail_hip((int)e, "gcn_gemm_atg256_f32 launch");
     return 0;
@@ -2539,14 +2578,23 @@ int gcn_gemm_atg256_f32(const float *A, int64_t lda, const int32_t *rows_a, cons
                         size_t workspace_bytes, void *stream)
 {
     return atg256_launch(0, A, lda, rows_a, G, ldg, rows_g, n_list, a_absmax_bound, g_absmax_bound, out, ldo,
-                         workspace, workspace_bytes, stream);
+                         nullptr, workspace, workspace_bytes, stream);
 }
 
 int gcn_gemm_atg256_f32_b3(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
                            const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, void *workspace,
                            size_t workspace_bytes, void *stream)
 {
-    return atg256_launch(1, A, lda, rows_a, G, ldg, rows_g, n_list, nullptr, nullptr, out, ldo, workspace,
+    return atg256_launch(1, A, lda, rows_a, G, ldg, rows_g, n_list, nullptr, nullptr, out, ldo, nullptr, workspace,
+                         workspace_bytes, stream);
+}
+
+int gcn_gemm_atg256_f32_b3_colsum(const float *A, int64_t lda, const int32_t *rows_a, const float *G, int64_t ldg,
+                                  const int32_t *rows_g, int64_t n_list, float *out, int64_t ldo, float *colsum_g,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (colsum_g == nullptr) return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_atg256_f32_b3_colsum: NULL colsum_g");
+    return atg256_launch(1, A, lda, rows_a, G, ldg, rows_g, n_list, nullptr, nullptr, out, ldo, colsum_g, workspace,
                          workspace_bytes, stream);
 }
 

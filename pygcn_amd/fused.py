@@ -277,14 +277,21 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
             gh_max = gh_max * ctx.scale
         del gh1
     del h1c, grad_sup2
-    if ctx.has_bias[0] and need_b1:
+    gpre_bound = gh_max if f32 else None
+    want_b1 = ctx.has_bias[0] and need_b1
+    if want_b1 and ctx.reassoc and need_w1 and f32:
+        # grad_W1 and grad_b1 from ONE pass over grad_pre1: the weight-gradient kernel sums the rows it loads
+        both = _spmm.weight_grad_rows(x, gpre1, rs.rows2_padded, None, ctx.z_bound, gpre_bound, n_list=rs.n2,
+                                      colsum_g=True)
+        if both is not None:
+            grad_w1, grad_b1 = both[0], both[1].to(ctx.bias_dtypes[0])
+    if want_b1 and grad_b1 is None:
         sums = _spmm.backward_with_colsum(gpre1) if gpre1.is_contiguous() else None   # (one HIP pass)
         grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])
-    gpre_bound = gh_max if f32 else None
     # ---- layer 1
     if ctx.reassoc:
         z = x                                           # this step's Â·X, saved by forward
-        if need_w1:
+        if need_w1 and grad_w1 is None:
             grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, ctx.z_bound,
                                              gpre_bound, n_list=rs.n2)
             if grad_w1 is None:
@@ -381,13 +388,18 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
             gh_max = gh_max * ctx.scale
         del gh1
     del grad_sup2
-    if ctx.has_bias[0] and need_b1:
+    gpre_bound = gh_max if f32 else None
+    want_b1 = ctx.has_bias[0] and need_b1
+    if want_b1 and ctx.reassoc and need_w1 and fast and x.shape[1] == 256:
+        both = _spmm.weight_grad_rows(x, gpre1, None, None, ctx.z_bound, gpre_bound, colsum_g=True)   # (one pass for both)
+        if both is not None:
+            grad_w1, grad_b1 = both[0], both[1].to(ctx.bias_dtypes[0])
+    if want_b1 and grad_b1 is None:
         sums = _spmm.backward_with_colsum(gpre1) if gpre1.is_contiguous() else None   # (one HIP pass)
         grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])
-    gpre_bound = gh_max if f32 else None
     if ctx.reassoc:
         z = x
-        if need_w1:
+        if need_w1 and grad_w1 is None:
             grad_w1 = _spmm.weight_grad_rows(z, gpre1, None, None, ctx.z_bound, gpre_bound) \
                 if ((fast and z.shape[1] == 256) or not f32) else None
             if grad_w1 is None:

@@ -673,7 +673,7 @@ def _identity_list(n, device):
     return have
 
 
-def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None):
+def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None, colsum_g=False):
     """Σ_r A[rows_a[r]]ᵀ ⊗ G[rows_g[r]] through the gather-fused MFMA kernels: the weight gradient
     `inputᵀ · grad_support` over a LIST of rows, without compacting either operand first.
     fp32 [*, 256] x [*, 256] (C-ABI gcn_gemm_atg256_f32_b3: three bf16 parts, fp32-equivalent — or
@@ -683,8 +683,13 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     longer than `n_list` (padding to a multiple of 16, padded_row_list()); unpadded lists are
     padded here.  *_bound (fp32 only): DEVICE float [1] upper bounds of max|A|, max|G| (computed
     here by a reduction pass over the listed rows when missing).  None if the operands do not fit
-    a kernel."""
+    a kernel.
+    colsum_g=True (fp32, default scheme): returns (grad_w, Σ_r G[rows_g[r]] as fp32 [256]) — the layer's bias
+    gradient from the rows the kernel loads anyway (C-ABI gcn_gemm_atg256_f32_b3_colsum); None where that
+    form does not exist (the caller then sums G itself)."""
     bf16 = A.dtype == torch.bfloat16 and G.dtype == torch.bfloat16
+    if colsum_g and (bf16 or _gemm_scheme != "bf16x3"):
+        return None
     if bf16:
         if (not A.is_cuda or A.dim() != 2 or G.dim() != 2 or A.stride(1) != 1 or G.stride(1) != 1
                 or A.stride(0) % 2 or G.stride(0) % 2 or A.data_ptr() % 4 or G.data_ptr() % 4
@@ -701,7 +706,8 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
             raise RuntimeError("weight_grad_rows: the two operands list different numbers of rows")
         n_list = n_a
     if n_list == 0:
-        return torch.zeros((A.shape[1], G.shape[1]), dtype=A.dtype, device=A.device)
+        zero = torch.zeros((A.shape[1], G.shape[1]), dtype=A.dtype, device=A.device)
+        return (zero, torch.zeros(G.shape[1], dtype=torch.float32, device=A.device)) if colsum_g else zero
     lists = []
     for r, t in ((rows_a, A), (rows_g, G)):
         if r is None:
@@ -729,6 +735,15 @@ def weight_grad_rows(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None,
     out = torch.empty((256, 256), dtype=torch.float32, device=A.device)
     ws_bytes = L.gcn_gemm_atg256_workspace_bytes(n_list)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+    if colsum_g:
+        cs = torch.empty(256, dtype=torch.float32, device=A.device)
+        with torch.cuda.device(A.device):
+            rc = L.gcn_gemm_atg256_f32_b3_colsum(A.data_ptr(), A.stride(0), lists[0].data_ptr(),
+                                                 G.data_ptr(), G.stride(0), lists[1].data_ptr(), n_list,
+                                                 out.data_ptr(), out.stride(0), cs.data_ptr(), ws.data_ptr(),
+                                                 ws_bytes, torch.cuda.current_stream().cuda_stream)
+        _native.check(rc, "gcn_gemm_atg256_f32_b3_colsum")
+        return out, cs
     if _gemm_scheme != "h2":            # three bf16 parts: no bounds
         with torch.cuda.device(A.device):
             rc = L.gcn_gemm_atg256_f32_b3(A.data_ptr(), A.stride(0), lists[0].data_ptr(),

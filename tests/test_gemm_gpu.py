@@ -235,6 +235,40 @@ def test_weight_gradient_over_row_lists_matches_fp64(dev, M, gemm_scheme):
     assert torch.equal(weight_grad_rows(Ap, G, ra, rg), got)
 
 
+@pytest.mark.parametrize("M", [1, 17, 100, 5000, 400_003])
+def test_weight_gradient_with_the_bias_gradient_as_a_side_result(dev, M):
+    """gcn_gemm_atg256_f32_b3_colsum: the weight gradient unchanged (same bits) and Σ_r G[rg[r]] — the layer's
+    bias gradient (pygcn/layers.py:36) — from the rows the kernel loads anyway: against a float64 sum, with and
+    without row lists, poisoned unlisted rows, lists that end inside a 32-row super-step and a 16-entry pad."""
+    from pygcn_amd import spmm as S
+    gen = torch.Generator(device=dev).manual_seed(M + 7)
+    n_g = 2 * M + 3
+    A = torch.randn(M, 256, generator=gen, device=dev)
+    G = torch.randn(n_g, 256, generator=gen, device=dev) * 0.01 + 0.003          # (sums that do not cancel to zero)
+    rg = torch.randperm(n_g, generator=gen, device=dev)[:M].to(torch.int32)
+    before = S.gemm_scheme()
+    S.set_gemm_scheme("bf16x3")
+    try:
+        plain = S.weight_grad_rows(A, G, None, rg)
+        both = S.weight_grad_rows(A, G, None, rg, colsum_g=True)
+        assert both is not None and torch.equal(both[0], plain)
+        ref = G[rg.long()].double().sum(0)
+        scale = float(G[rg.long()].double().abs().sum(0).max())
+        assert both[1].shape == (256,) and both[1].dtype == torch.float32
+        assert float((both[1].double() - ref).abs().max()) <= 2e-7 * scale, float((both[1].double() - ref).abs().max()) / scale
+        Gp = torch.full_like(G, float("nan"))
+        Gp[rg.long()] = G[rg.long()]
+        again = S.weight_grad_rows(A, Gp, None, rg, colsum_g=True)
+        assert torch.equal(again[0], plain) and torch.equal(again[1], both[1])
+        Gc = G[rg.long()].contiguous()                                           # no list at all
+        dense = S.weight_grad_rows(A, Gc, colsum_g=True)
+        assert torch.equal(dense[0], plain) and float((dense[1].double() - ref).abs().max()) <= 2e-7 * scale
+        S.set_gemm_scheme("h2")                                                  # (the two-part scheme has no such form)
+        assert S.weight_grad_rows(A, G, None, rg, colsum_g=True) is None
+    finally:
+        S.set_gemm_scheme(before)
+
+
 def test_weight_gradient_degenerate_lists(dev):
     from pygcn_amd.spmm import weight_grad_rows
     A, G = torch.randn(10, 256, device=dev), torch.randn(10, 256, device=dev)
