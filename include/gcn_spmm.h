@@ -72,7 +72,9 @@ typedef struct gcn_csr_plan {
     const int32_t *long_chunk0;/* [n_long+1] first chunk of every long row                   */
 } gcn_csr_plan;
 
-/* ABI history: 21 = round 2's surface.  24 (round 4): new entry points gcn_gemm_xw256_f32_b3 /
+/* ABI history: 21 = round 2's surface.  25 (round 4, late): new entry point gcn_gemm_atg256_f32_b3_colsum (the
+ * weight gradient with the bias gradient Σ G[rows] as a side result); gcn_gemm_atg256_workspace_bytes grew by
+ * 1 KiB per workgroup; nothing else changed.  24 (round 4): new entry points gcn_gemm_xw256_f32_b3 /
  * gcn_gemm_atg256_f32_b3 (the fp32-EQUIVALENT three-part bf16 form of the 256-wide GEMMs with the
  * full option set of the _h2 entry points: row lists, forward epilogue, backward mask, max|Y|) and
  * gcn_gemm_xw256_b3_workspace_bytes; nothing existing changed.  23 (round 3, late): at p = 1/2 the dropout keep function
