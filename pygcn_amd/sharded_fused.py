@@ -204,10 +204,16 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
                                 torch.zeros((), dtype=dt, device=dev))
             if gh_max is not None:
                 gh_max = gh_max * ctx.scale
-        if ctx.has_bias[0] and need_b1:
+        want_b1 = ctx.has_bias[0] and need_b1
+        if want_b1 and need_w1 and fast and rs.n2 > 0:          # (grad_W1 and grad_b1 from one pass over grad_pre1)
+            both = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, ctx.z_bound, gh_max if f32 else None,
+                                          n_list=rs.n2, colsum_g=True)
+            if both is not None:
+                grad_w1, grad_b1 = both[0], both[1].to(ctx.bias_dtypes[0])
+        if want_b1 and grad_b1 is None:
             sums = _spmm.backward_with_colsum(gpre1) if (gpre1.is_contiguous() and rs.n2) else None
             grad_b1 = (sums[1] if sums is not None else gpre1.float().sum(0)).to(ctx.bias_dtypes[0])
-        if need_w1:
+        if need_w1 and grad_w1 is None:
             grad_w1 = _spmm.weight_grad_rows(z, gpre1, rs.rows2_padded, None, ctx.z_bound,
                                              gh_max if f32 else None, n_list=rs.n2) \
                 if (fast or (not f32 and rs.n2 > 0)) else None
