@@ -74,7 +74,8 @@ typedef struct gcn_csr_plan {
 
 /* ABI history: 21 = round 2's surface.  25 (round 4, late): new entry point gcn_gemm_atg256_f32_b3_colsum (the
  * weight gradient with the bias gradient Σ G[rows] as a side result); gcn_gemm_atg256_workspace_bytes grew by
- * 1 KiB per workgroup; nothing else changed.  24 (round 4): new entry points gcn_gemm_xw256_f32_b3 /
+ * 1 KiB per workgroup; struct gcn_gemm_epilogue gained keep_bits_out / mask_bits at its END (zero them);
+ * nothing else changed.  24 (round 4): new entry points gcn_gemm_xw256_f32_b3 /
  * gcn_gemm_atg256_f32_b3 (the fp32-EQUIVALENT three-part bf16 form of the 256-wide GEMMs with the
  * full option set of the _h2 entry points: row lists, forward epilogue, backward mask, max|Y|) and
  * gcn_gemm_xw256_b3_workspace_bytes; nothing existing changed.  23 (round 3, late): at p = 1/2 the dropout keep function
@@ -416,6 +417,15 @@ typedef struct gcn_gemm_epilogue {
     const int32_t *mask_rows;
     /* added to the row index in the dropout counter (see struct gcn_epilogue; ABI 22) */
     int64_t drop_row_base;
+    /* ABI 25, gcn_gemm_xw256_f32_b3 on CONTIGUOUS rows only (x_rows NULL; GCN_E_BADARG otherwise): the result of
+     * the forward epilogue as ONE BIT per element — `out > 0`, which is all the backward of ReLU / dropout asks
+     * of `out` — 32 bytes per row (DEVICE uint32 [M][8], 8-byte aligned) in the kernel's own lane order (an
+     * opaque layout: only mask_bits of the same entry point reads it).  keep_bits_out: written next to Y by a
+     * launch with relu and dropout_p in {0, 1/2}.  mask_bits: the backward mask read from such bits (row
+     * mask_rows[r], or r) INSTEAD of mask_src — 32 bytes per row instead of 1 KiB; excludes the forward
+     * epilogue like mask_src; mask_scale applies. */
+    uint32_t *keep_bits_out;
+    const uint32_t *mask_bits;
 } gcn_gemm_epilogue;
 
 size_t gcn_gemm_xw256_h2_workspace_bytes(void);

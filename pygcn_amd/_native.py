@@ -55,7 +55,8 @@ class GcnGemmEpilogue(ctypes.Structure):
                 ("seed", ctypes.c_uint64), ("seed_dev", ctypes.c_void_p),
                 ("mask_src", ctypes.c_void_p), ("ld_mask", ctypes.c_int64),
                 ("mask_scale", ctypes.c_float), ("mask_rows", ctypes.c_void_p),
-                ("drop_row_base", ctypes.c_int64)]
+                ("drop_row_base", ctypes.c_int64), ("keep_bits_out", ctypes.c_void_p),
+                ("mask_bits", ctypes.c_void_p)]
 
 
 # every symbol include/gcn_spmm.h declares (tests check that the library exports all of them)

@@ -441,6 +441,12 @@ struct H2Epi {
     int64_t ld_mask;
     const int32_t *mask_rows;   // optional: mask row of output row r (default: its input row)
     float mask_scale;
+    // (gemm_xw256_s16_kernel only) the ReLU / dropout result as ONE BIT per element, 32 bytes per row, in the
+    // kernel's own lane order: row r, lane quarter q (0..3), word w (0..1): bit 4 (cb & 7) + j of word
+    // 2 q + w at r * 8 words <-> column 16 (8 w + (cb & 7)) + 4 q + j.  Written by the forward epilogue
+    // (keep_bits_out), read by the backward mask (mask_bits, instead of 1 KiB of mask_src per row).
+    uint32_t *keep_bits_out;
+    const uint32_t *mask_bits;
 };
 
 // Philox4x32-10 — the SAME keep function of (seed, row, f) as the SpMM epilogue (gcn_spmm.hip,
@@ -1055,8 +1061,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
     const float *__restrict__ X, int64_t ldx, const unsigned char *__restrict__ ws, float *__restrict__ Y,
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
-    // EPI as in gemm_xw256_h2_kernel: 0 plain, 2 backward mask, 1 bias, 4 + ReLU, 5 + dropout at 1/2, 6 + dropout at p
-    constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASKED = EPI == 2;
+    // EPI as in gemm_xw256_h2_kernel: 0 plain, 2 backward mask, 1 bias, 4 + ReLU, 5 + dropout at 1/2, 6 + dropout at p;
+    // 3: backward mask from KEEP BITS (H2Epi::mask_bits: 8 bytes per lane and tile instead of 16 x 16)
+    constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASKED = EPI == 2, MASK_BITS = EPI == 3;
     constexpr bool RELU = EPI >= 4, DROP1 = EPI == 5, DROP16 = EPI == 6;
     static_assert(kWaves == 8, "written for eight waves");
     constexpr int kSt = kS16StageBytes, kWShare = kSt / kWaves;          // a wave's part of a stage: 6 KiB
@@ -1145,6 +1152,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
     int64_t ptile = 0;
     bool have_prev = false;
     [[maybe_unused]] uint32_t r1[4] = {0u, 0u, 0u, 0u};          // dropout at 1/2: the row's keep bits (one Philox call)
+    [[maybe_unused]] uint32_t kb[2] = {0u, 0u};                  // forward: this lane's 64 result bits of the tile being stored
+    // backward mask from bits: the 8 bytes of this lane for the tile being STORED (mb_prev), being multiplied
+    // (mb_cur) and the one after (mb_next, requested at the top of a tile: a whole tile ahead of its use)
+    [[maybe_unused]] uint32_t mb_prev[2] = {0u, 0u}, mb_cur[2] = {0u, 0u}, mb_next[2] = {0u, 0u};
+    [[maybe_unused]] int32_t mrow_next = 0;                      // the mask row of this lane's row in the NEXT tile
+    auto mask_row_of = [&](int64_t t) -> int32_t {               // (rows past the end: row 0 of the mask, never used)
+        const int64_t row = t * kS16Rows + lrow;
+        return (t >= n_tiles || row >= M) ? 0 : (ep.mask_rows != nullptr ? ep.mask_rows[row] : (int32_t)row);
+    };
+    auto bits_load = [&](int32_t mrow, uint32_t (&dst)[2]) {
+        const uint2 w = *(const uint2 *)(ep.mask_bits + (int64_t)mrow * 8 + 2 * q);
+        dst[0] = w.x;
+        dst[1] = w.y;
+    };
+    auto bits_store = [&](int64_t t) {                           // after the tile's 16th column block
+        if (RELU && ep.keep_bits_out != nullptr)
+            *(uint2 *)(ep.keep_bits_out + (t * kS16Rows + lrow) * 8 + 2 * q) = uint2{kb[0], kb[1]};
+    };
     [[maybe_unused]] int64_t pmask_row = 0;                      // masked form: the mask row of this lane's prev row
     auto finish = [&](int cb, f32x4 v, const f32x4 &mk, int64_t drow) __attribute__((always_inline)) -> f32x4 {
         const int f = 16 * cb + 4 * q;                           // first of this lane's 4 columns
@@ -1182,6 +1207,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
             v.z = mk.z > 0.f ? v.z * mask_scale : 0.f;
             v.w = mk.w > 0.f ? v.w * mask_scale : 0.f;
         }
+        if (MASK_BITS) {
+            const uint32_t nib = mb_prev[cb >> 3] >> (4 * (cb & 7));
+            v.x = (nib & 1u) ? v.x * mask_scale : 0.f;
+            v.y = (nib & 2u) ? v.y * mask_scale : 0.f;
+            v.z = (nib & 4u) ? v.z * mask_scale : 0.f;
+            v.w = (nib & 8u) ? v.w * mask_scale : 0.f;
+        }
+        if (RELU && ep.keep_bits_out != nullptr) {                 // (uniform) what the backward mask will ask: out > 0
+            const uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            kb[cb >> 3] = (cb & 7) == 0 ? nib : (kb[cb >> 3] | (nib << (4 * (cb & 7))));
+        }
         if (y_absmax != nullptr) {                                 // (wave-uniform)
             if (RELU)
                 vmax = max(max(vmax, max(__float_as_uint(v.x), __float_as_uint(v.y))),
@@ -1210,6 +1246,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         mk[1] = *(const f32x4 *)(mrow + 16);
     };
 
+    if (MASK_BITS) {                                           // (once: a dependent pair of loads)
+        bits_load(mask_row_of(tile), mb_cur);
+        mrow_next = mask_row_of(tile + gridDim.x);
+    }
     for (; tile < n_tiles; tile += gridDim.x) {
         const bool has_next = tile + gridDim.x < n_tiles;      // (uniform)
         asm volatile("" : "+s"(wl));                           // (no hoisting of the W image's addresses)
@@ -1224,6 +1264,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
             __builtin_amdgcn_s_barrier();
             GEMM_STAMP(st_b);
             st_bw += st_b - st_a;
+            if (MASK_BITS && c == 0) {
+                // the NEXT tile's bits (its mask row was looked up a tile ago) and the mask row of the one after
+                bits_load(mrow_next, mb_next);
+                mrow_next = mask_row_of(tile + 2 * (int64_t)gridDim.x);
+            }
             auto store_one = [&](int u) __attribute__((always_inline)) {  // column block 2c + u of the previous tile (always a full tile)
                 if (have_prev) {
                     float *ybase = Y + ptile * kS16Rows * ldy;                          // (uniform)
@@ -1231,6 +1276,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
                     const int cb = 2 * c + u;
                     const f32x4 v = finish(cb, prev[cb], mk[u], drow);
                     if (!(S16_ABLATE & 1) || v.x == 1.2345e-30f) *(f32x4 *)(ybase + yoff + 16 * cb) = v;
+                    if (cb == 15) bits_store(ptile);
                 }
             };
             auto stores = [&]() __attribute__((always_inline)) { store_one(0); store_one(1); };
@@ -1243,7 +1289,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
             }
             const bool issued_w = (c + 1 < kS16Stages) || has_next;
             const bool issued_x = (c + 2 < kS16Stages) || has_next;
-            constexpr bool SPREAD = S16_SPREAD && !MASKED;
+            constexpr bool SPREAD = S16_SPREAD && !MASKED;          // (MASK_BITS loads nothing in its stages: it spreads)
             auto w_issue_all = [&]() {
                 if (c + 1 < kS16Stages) w_issue(c + 1, (c + 1) & 1);
                 else if (has_next) w_issue(0, 0);                // the next tile's first stage
@@ -1339,6 +1385,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         ptile = tile;
         have_prev = true;
         st_n += 1;
+        if (MASK_BITS) {
+            mb_prev[0] = mb_cur[0]; mb_prev[1] = mb_cur[1];
+            mb_cur[0] = mb_next[0]; mb_cur[1] = mb_next[1];
+        }
         capture(tile);
         if (MASKED && has_next) mask_load(0);
     }
@@ -1358,6 +1408,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
             }
             if (DROP16) __builtin_amdgcn_sched_barrier(0);
         }
+        bits_store(ptile);
     }
     if (y_absmax != nullptr) {
 #pragma unroll
@@ -2280,7 +2331,7 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: dropout_p must be in [0, 1)");
         if (epi->dropout_p > 0.f && !epi->relu)
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: dropout needs relu (out > 0 encodes the mask)");
-        if (mask_src != nullptr && (epi->bias != nullptr || epi->relu || epi->dropout_p > 0.f))
+        if ((mask_src != nullptr || epi->mask_bits != nullptr) && (epi->bias != nullptr || epi->relu || epi->dropout_p > 0.f))
             return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: forward epilogue and backward mask exclude each other");
         ep.bias = epi->bias;
         ep.relu = epi->relu ? 1 : 0;
@@ -2292,8 +2343,10 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
         ep.seed_dev = epi->seed_dev;
         ep.mask_src = mask_src;
         ep.ld_mask = ld_mask;
-        ep.mask_rows = mask_src != nullptr ? epi->mask_rows : nullptr;
+        ep.mask_rows = (mask_src != nullptr || epi->mask_bits != nullptr) ? epi->mask_rows : nullptr;
         ep.mask_scale = epi->mask_scale;
+        ep.keep_bits_out = epi->keep_bits_out;
+        ep.mask_bits = epi->mask_bits;
     }
     if (M < 0 || ldx < kK || ldy < kN || ldw < kN)
         return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_h2: bad sizes");
@@ -2316,11 +2369,18 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
     // instantiation by store section (compile-time options, see the kernels): 0 plain, 2 backward mask,
     // 1 bias, 4 bias + ReLU, 5 + dropout at p = 1/2 (one-bit keep fields), 6 + dropout at another p
     const bool fwd = ep.bias != nullptr || ep.relu || ep.drop_thresh != 0u;
-    const int variant = !fwd ? (ep.mask_src != nullptr ? 2 : 0)
+    const int variant = !fwd ? (ep.mask_bits != nullptr ? 3 : (ep.mask_src != nullptr ? 2 : 0))
                              : (!ep.relu ? 1 : (ep.drop_thresh == 0u ? 4 : (ep.drop_thresh == 32768u ? 5 : 6)));
     // (s16 addresses a tile's rows as 32-bit offsets from the tile origin, takes no row list, and has no
     //  instantiation for dropout at p != 1/2)
     const bool s16 = sch == 1 && GEMM_B3_S16 && x_rows == nullptr && variant != 6 && ldx < (1 << 21) && ldy < (1 << 21);
+    // (the one-bit mask exists in the contiguous-row kernel's lane order only: a launch that cannot take that kernel
+    //  must be given mask_src / no keep_bits_out — refuse rather than ignore)
+    if ((ep.mask_bits != nullptr || ep.keep_bits_out != nullptr) &&
+        !(s16 && (ep.mask_bits != nullptr ? !fwd : (ep.relu != 0)) &&
+          (((uintptr_t)ep.mask_bits) | ((uintptr_t)ep.keep_bits_out)) % 8 == 0))
+        return gcn_internal_fail(GCN_E_BADARG, "gcn_gemm_xw256_f32_b3: keep_bits_out / mask_bits need contiguous rows, the three-part "
+                                               "scheme, ReLU with dropout_p in {0, 1/2} (forward) or no forward epilogue (backward)");
     if (sch == 0)
         hipLaunchKernelGGL(split_w_h2_kernel, dim3(1), dim3(1024), 0, s, W, ldw, (unsigned char *)workspace);
     else if (s16)
@@ -2346,8 +2406,8 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
                 if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_h2: LDS size");
             }
             const void *tall[] = {(const void *)gemm_xw256_s16_kernel<0>, (const void *)gemm_xw256_s16_kernel<1>,
-                                  (const void *)gemm_xw256_s16_kernel<2>, (const void *)gemm_xw256_s16_kernel<4>,
-                                  (const void *)gemm_xw256_s16_kernel<5>};
+                                  (const void *)gemm_xw256_s16_kernel<2>, (const void *)gemm_xw256_s16_kernel<3>,
+                                  (const void *)gemm_xw256_s16_kernel<4>, (const void *)gemm_xw256_s16_kernel<5>};
             for (const void *k : tall) {
                 hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS16LdsBytes);
                 if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_b3: LDS size");
@@ -2372,6 +2432,10 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
     case 0: GCN_LAUNCH_H2(0); break;
     case 1: GCN_LAUNCH_H2(1); break;
     case 2: GCN_LAUNCH_H2(2); break;
+    case 3:          // (s16 only: checked above)
+        hipLaunchKernelGGL((gemm_xw256_s16_kernel<3>), dim3(grid), dim3(kThreads), dyn, s, X, ldx,
+                           (const unsigned char *)workspace, Y, ldy, M, (uint32_t *)y_absmax, ep);
+        break;
     case 4: GCN_LAUNCH_H2(4); break;
     case 5: GCN_LAUNCH_H2(5); break;
     default: GCN_LAUNCH_H2(6); break;

@@ -186,6 +186,7 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
     # pass needs for grad_W1 = zᵀ·grad_pre1: no second sparse product for layer 1 (12.7 ms at
     # C4, 35.5 ms at C5).
     ctx.reassoc = bool(_spmm.layer_gemm_reassociable(x, w1, b1))
+    ctx.keep_bits = None
     h1 = h_bound = z = None
     ctx.z_bound = None
     if ctx.reassoc:
@@ -193,10 +194,14 @@ def _gcn2_forward(ctx, x, w1, b1, w2, b2, graph, dropout_p, seed):
         if bounded:
             ctx.z_bound = graph.inf_norm() * ctx.x_bound * 1.0001
             h_bound = torch.zeros(1, dtype=torch.float32, device=x.device)   # max|h1|, exact
+        # `h1 > 0` — all the backward of ReLU / dropout asks of h1 — as one bit per element, written by the
+        # same launch where it can: the masked grad_input GEMM then reads 32 bytes per row instead of 1 KiB
+        if _spmm.gemm_keep_bits_usable(z, None, dropout_p) and any(ctx.needs_input_grad):
+            ctx.keep_bits = torch.empty((z.shape[0], 8), dtype=torch.int32, device=z.device)
         h1 = _spmm.layer_gemm(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, dropout_p=dropout_p,
-                              seed=seed)
+                              seed=seed, keep_bits_out=ctx.keep_bits)
         if h1 is None:                     # (alignment the kernel cannot take)
-            ctx.reassoc, z, h_bound = False, None, None
+            ctx.reassoc, z, h_bound, ctx.keep_bits = False, None, None, None
     if h1 is None:
         s_max = torch.zeros(1, dtype=torch.float32, device=x.device) if bounded else None
         sup1 = _dense_forward(x, w1, ctx.x_bound, s_max)
@@ -265,6 +270,7 @@ def _gcn2_backward_rows(ctx, x, w1, w2, h1, out_rows, rs, grad_rows, needs):
     gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
     w2t = w2.t().contiguous()
     gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_rows=rs.rows2_i32,
+                       mask_bits=getattr(ctx, "keep_bits", None),
                        mask_scale=ctx.scale) if fast else None
     if gpre1 is None and dt == torch.bfloat16:       # (C5: the bf16 GEMM carries the mask too)
         gpre1 = _spmm.gemm_bf16(grad_sup2, w2t, mask_src=h1, mask_rows=rs.rows2_i32, mask_scale=ctx.scale)
@@ -378,7 +384,8 @@ def _gcn2_backward_dense(ctx, x, w1, w2, h1, logp, grad, needs):
             grad_w2 = _weight_grad(h1, grad_sup2)
     gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
     w2t = w2.t().contiguous()
-    gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_scale=ctx.scale) if fast else None
+    gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_scale=ctx.scale,
+                       mask_bits=getattr(ctx, "keep_bits", None)) if fast else None
     if gpre1 is None and dt == torch.bfloat16:       # (C5: the bf16 GEMM carries the mask in its store too)
         gpre1 = _spmm.gemm_bf16(grad_sup2, w2t, mask_src=h1, mask_scale=ctx.scale)
     if gpre1 is None:

@@ -475,8 +475,17 @@ class SpMMFunction(torch.autograd.Function):
         return None, grad_B, grad_bias, None, None, None
 
 
+def gemm_keep_bits_usable(X, rows=None, dropout_p=0.0):
+    """Does gemm_xw256 run this operand on the kernel that can write / read the ONE-BIT form of a ReLU /
+    dropout result (C-ABI gcn_gemm_epilogue.keep_bits_out / mask_bits: contiguous rows, the three-part
+    scheme, dropout_p in {0, 1/2})?"""
+    return (_gemm_scheme == "bf16x3" and rows is None and X.dtype == torch.float32 and X.is_cuda and X.dim() == 2
+            and X.shape[1] == 256 and X.stride(1) == 1 and X.stride(0) < (1 << 21) and dropout_p in (0.0, 0.5))
+
+
 def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0,
-               bias=None, relu=False, dropout_p=0.0, seed=0, mask_rows=None, row_base=0):
+               bias=None, relu=False, dropout_p=0.0, seed=0, mask_rows=None, row_base=0,
+               keep_bits_out=None, mask_bits=None):
     """X[M,256] · W[256,256] through the hand-written MFMA kernels (fp32 in/out, fp32-level
     accuracy).  None if the operands do not fit the kernels' fixed shape / alignment (the caller
     then uses torch.mm — hipBLASLt).
@@ -496,6 +505,9 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     `bias` / `relu` / `dropout_p` / `seed`: FORWARD epilogue in the store, y = dropout(relu(acc +
     bias)) with the same Philox keep function as the SpMM epilogue — for a layer evaluated as
     (Â·X)·W + b, whose last stage is the GEMM (None if it cannot be fused).
+    `keep_bits_out` (int32 [M, 8], with relu; only where gemm_keep_bits_usable()): the launch also writes
+    `out > 0` as one bit per element; `mask_bits` (such a tensor, given NEXT TO mask_src): the backward mask
+    is read from the bits (32 bytes per row instead of 1 KiB) where the launch can, from mask_src where not.
     Both schemes carry every option; "bf16x3" keeps full accuracy for 1e-30 <= |x| <= 3e38 (below
     that its low-order parts underflow — tests/test_gemm_gpu.py)."""
     if (_gemm_scheme == "exact" or X.dtype != torch.float32 or W.dtype != torch.float32 or not X.is_cuda
@@ -524,6 +536,17 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
     Y = torch.empty((m_out, 256), dtype=torch.float32, device=X.device)
     if m_out == 0:
         return Y
+    for t, name in ((keep_bits_out, "keep_bits_out"), (mask_bits, "mask_bits")):
+        if t is not None and (t.dtype != torch.int32 or t.dim() != 2 or t.shape[1] != 8 or not t.is_contiguous()
+                              or t.device != X.device):
+            raise RuntimeError(f"gemm_xw256: {name} must be a contiguous int32 [rows, 8] device tensor")
+    if keep_bits_out is not None and not (relu and keep_bits_out.shape[0] >= m_out
+                                          and gemm_keep_bits_usable(X, rows, dropout_p)
+                                          and Y.stride(0) < (1 << 21)):
+        raise RuntimeError("gemm_xw256: keep_bits_out needs relu, contiguous rows, the bf16x3 scheme and "
+                           "dropout_p in {0, 1/2} (gemm_keep_bits_usable)")
+    if mask_bits is not None and (mask_src is None or not gemm_keep_bits_usable(X, rows)):
+        mask_bits = None                      # (this launch reads the mask itself)
     if x_bound is None and _gemm_scheme == "h2":
         # no bound known: one reduction pass over X (1.4 ms at M = 10^7) and the 5.4 ms kernel
         # still beat the 7.5 ms three-part kernel — and keep full accuracy for tiny operands,
@@ -534,15 +557,18 @@ def gemm_xw256(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask
         ep = None
         if has_fwd_ep or mask_src is not None:
             seed_dev = None
+            by_bits = mask_bits is not None
             if isinstance(seed, torch.Tensor):       # device-resident seed (hipGraph capture)
                 seed_dev, seed = seed.data_ptr(), 0
             ep = _native.GcnGemmEpilogue(
                 bias.detach().data_ptr() if bias is not None else None, int(bool(relu)),
                 float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev,
-                mask_src.data_ptr() if mask_src is not None else None,
-                mask_src.stride(0) if mask_src is not None else 0, float(mask_scale),
+                mask_src.data_ptr() if (mask_src is not None and not by_bits) else None,
+                mask_src.stride(0) if (mask_src is not None and not by_bits) else 0, float(mask_scale),
                 mask_rows.data_ptr() if (mask_rows is not None and mask_src is not None) else None,
-                int(row_base))
+                int(row_base),
+                keep_bits_out.data_ptr() if keep_bits_out is not None else None,
+                mask_bits.data_ptr() if by_bits else None)
         if _gemm_scheme == "h2":
             if x_bound.dtype != torch.float32 or x_bound.numel() != 1 or x_bound.device != X.device:
                 raise RuntimeError("gemm_xw256: x_bound must be one float32 on the operand's device")
@@ -637,11 +663,11 @@ def layer_gemm_reassociable(x, weight, bias):
 
 
 def layer_gemm(z, weight, z_bound=None, y_absmax=None, bias=None, relu=False, dropout_p=0.0, seed=0,
-               row_base=0):
+               row_base=0, keep_bits_out=None):
     """epilogue(z·W + b) through the kernel layer_gemm_reassociable() promised (None if it declines)."""
     if z.dtype == torch.float32:
         return gemm_xw256(z, weight, z_bound, y_absmax, bias=bias, relu=relu, dropout_p=dropout_p,
-                          seed=seed, row_base=row_base)
+                          seed=seed, row_base=row_base, keep_bits_out=keep_bits_out)
     return gemm_bf16(z, weight, bias=bias, relu=relu, dropout_p=dropout_p, seed=seed, row_base=row_base)
 
 

@@ -344,6 +344,44 @@ def test_gemm_with_fused_relu_dropout_mask(dev, gemm_scheme):
     assert_normwise(got_r.cpu(), want[rows.long()].double().cpu().numpy(), 1e-6, "listed vs contiguous rows")
 
 
+@pytest.mark.parametrize("M", [1, 129, 4099, 300_007])
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_keep_bits_carry_the_backward_mask(dev, M, p):
+    """gcn_gemm_epilogue.keep_bits_out / mask_bits (ABI 25): the forward launch writes `out > 0` as one bit per
+    element, the grad_input launch masks from those bits — the SAME bits as masking from the fp32 activations,
+    with and without a mask row list; launches that cannot take the contiguous-row kernel read mask_src."""
+    from pygcn_amd import spmm as S
+    from pygcn_amd.spmm import gemm_xw256
+    gen = torch.Generator(device=dev).manual_seed(M + int(10 * p))
+    X = torch.randn(M, 256, generator=gen, device=dev)
+    W = torch.randn(256, 256, generator=gen, device=dev) * 0.1
+    G = torch.randn(M, 256, generator=gen, device=dev)
+    bias = torch.randn(256, generator=gen, device=dev) * 0.5
+    before = S.gemm_scheme()
+    S.set_gemm_scheme("bf16x3")
+    try:
+        assert S.gemm_keep_bits_usable(X, None, p)
+        bits = torch.full((M, 8), -1, dtype=torch.int32, device=dev)
+        H = gemm_xw256(X, W, bias=bias, relu=True, dropout_p=p, seed=77, keep_bits_out=bits)
+        assert torch.equal(H, gemm_xw256(X, W, bias=bias, relu=True, dropout_p=p, seed=77))    # Y itself unchanged
+        assert int((H > 0).sum()) == int(sum(((bits >> k) & 1).sum() for k in range(32)))     # as many bits as positives
+        want = gemm_xw256(G, W, mask_src=H, mask_scale=1.5)
+        got = gemm_xw256(G, W, mask_src=H, mask_scale=1.5, mask_bits=bits)
+        assert torch.equal(got, want)
+        poisoned = torch.full_like(H, float("nan"))                      # with bits, the activations are not read
+        assert torch.equal(gemm_xw256(G, W, mask_src=poisoned, mask_scale=1.5, mask_bits=bits), want)
+        perm = torch.randperm(M, device=dev).to(torch.int32)
+        want_p = gemm_xw256(G, W, mask_src=H, mask_rows=perm, mask_scale=1.5)
+        assert torch.equal(gemm_xw256(G, W, mask_src=poisoned, mask_rows=perm, mask_scale=1.5, mask_bits=bits), want_p)
+        rows = torch.arange(M, device=dev, dtype=torch.int32)            # a row list: the other kernel, mask_src is read
+        assert torch.equal(gemm_xw256(G, W, rows=rows, mask_src=H, mask_scale=1.5, mask_bits=bits),
+                           gemm_xw256(G, W, rows=rows, mask_src=H, mask_scale=1.5))
+        with pytest.raises(RuntimeError):
+            gemm_xw256(X, W, bias=bias, relu=True, dropout_p=0.3, seed=77, keep_bits_out=bits)
+    finally:
+        S.set_gemm_scheme(before)
+
+
 @pytest.mark.parametrize("p", [0.0, 0.3, 0.5])
 def test_gemm_forward_epilogue_matches_the_spmm_epilogue(dev, p, gemm_scheme):
     """bias + ReLU + inverted dropout in the GEMM's store (a layer evaluated as (Â·X)·W + b): the
