@@ -122,6 +122,11 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
             ctx.z_bound = sg.A.inf_norm() * sg.constant_absmax(x_local) * 1.0001
             h_bound = torch.zeros(1, dtype=torch.float32, device=x_local.device)
         kw = {"dropout_p": dropout_p, "seed": seed, "row_base": sg.r0} if dropout_p > 0.0 else {}
+        # (`h1 > 0` as one bit per element for the masked grad_input GEMM: pygcn_amd/fused.py)
+        ctx.keep_bits = None
+        if f32 and _spmm.gemm_keep_bits_usable(z, None, dropout_p) and any(ctx.needs_input_grad):
+            ctx.keep_bits = torch.empty((z.shape[0], 8), dtype=torch.int32, device=z.device)
+            kw = dict(kw, keep_bits_out=ctx.keep_bits)
         h1 = _spmm.layer_gemm(z, w1, ctx.z_bound, h_bound, bias=b1, relu=True, **kw)
         if h1 is None:
             raise RuntimeError("sharded one-node path: the layer GEMM declined the operands")
@@ -194,7 +199,7 @@ class ShardedGCN2RowsFunction(torch.autograd.Function):
         gh_max = torch.zeros(1, dtype=torch.float32, device=dev) if f32 else None
         w2t = w2.t().contiguous()
         gpre1 = gemm_xw256(grad_sup2, w2t, gs_bound, gh_max, mask_src=h1, mask_rows=rs.rows2_i32,
-                           mask_scale=ctx.scale) if fast else None
+                           mask_bits=getattr(ctx, "keep_bits", None), mask_scale=ctx.scale) if fast else None
         if gpre1 is None and dt == torch.bfloat16 and rs.n2:
             gpre1 = _spmm.gemm_bf16(grad_sup2, w2t, mask_src=h1, mask_rows=rs.rows2_i32, mask_scale=ctx.scale)
         if gpre1 is None:
