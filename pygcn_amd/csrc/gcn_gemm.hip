@@ -1056,14 +1056,16 @@ template <int OFF> __device__ __forceinline__ void dma16_s(const void *sbase, ui
                  :: "v"(voff), "s"(sbase), "s"(lds_addr), "n"(OFF) : "memory", "m0");
 }
 
-template <int EPI>
+template <int EPI, bool BITS = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
     const float *__restrict__ X, int64_t ldx, const unsigned char *__restrict__ ws, float *__restrict__ Y,
     int64_t ldy, int64_t M, uint32_t *__restrict__ y_absmax, const H2Epi ep)
 {
     // EPI as in gemm_xw256_h2_kernel: 0 plain, 2 backward mask, 1 bias, 4 + ReLU, 5 + dropout at 1/2, 6 + dropout at p;
     // 3: backward mask from KEEP BITS (H2Epi::mask_bits: 8 bytes per lane and tile instead of 16 x 16)
+    // BITS (with ReLU): the launch also writes `out > 0` as one bit per element (H2Epi::keep_bits_out)
     constexpr bool FWD_EPI = EPI == 1 || EPI >= 4, MASKED = EPI == 2, MASK_BITS = EPI == 3;
+    static_assert(!BITS || EPI == 4 || EPI == 5, "keep bits belong to the ReLU epilogues");
     constexpr bool RELU = EPI >= 4, DROP1 = EPI == 5, DROP16 = EPI == 6;
     static_assert(kWaves == 8, "written for eight waves");
     constexpr int kSt = kS16StageBytes, kWShare = kSt / kWaves;          // a wave's part of a stage: 6 KiB
@@ -1167,8 +1169,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
         dst[1] = w.y;
     };
     auto bits_store = [&](int64_t t) {                           // after the tile's 16th column block
-        if (RELU && ep.keep_bits_out != nullptr)
-            *(uint2 *)(ep.keep_bits_out + (t * kS16Rows + lrow) * 8 + 2 * q) = uint2{kb[0], kb[1]};
+        if (BITS) *(uint2 *)(ep.keep_bits_out + (t * kS16Rows + lrow) * 8 + 2 * q) = uint2{kb[0], kb[1]};
     };
     [[maybe_unused]] int64_t pmask_row = 0;                      // masked form: the mask row of this lane's prev row
     auto finish = [&](int cb, f32x4 v, const f32x4 &mk, int64_t drow) __attribute__((always_inline)) -> f32x4 {
@@ -1214,8 +1215,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
             v.z = (nib & 4u) ? v.z * mask_scale : 0.f;
             v.w = (nib & 8u) ? v.w * mask_scale : 0.f;
         }
-        if (RELU && ep.keep_bits_out != nullptr) {                 // (uniform) what the backward mask will ask: out > 0
-            const uint32_t nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+        if (BITS) {                                                // what the backward mask will ask: out > 0
+            // (out is max(., 0) times a positive scale or 0: never NaN — so out > 0 <=> its bits, as a SIGNED integer,
+            //  are >= 1: one v_med3_i32 per element — hipcc makes a compare + select + wait states of the C form)
+            auto pos = [](float f) {
+                uint32_t r;
+                asm("v_med3_i32 %0, %1, 0, 1" : "=v"(r) : "v"(__float_as_uint(f)));
+                return r;
+            };
+            const uint32_t nib = pos(v.x) | (pos(v.y) << 1) | (pos(v.z) << 2) | (pos(v.w) << 3);
             kb[cb >> 3] = (cb & 7) == 0 ? nib : (kb[cb >> 3] | (nib << (4 * (cb & 7))));
         }
         if (y_absmax != nullptr) {                                 // (wave-uniform)
@@ -2407,7 +2415,8 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
             }
             const void *tall[] = {(const void *)gemm_xw256_s16_kernel<0>, (const void *)gemm_xw256_s16_kernel<1>,
                                   (const void *)gemm_xw256_s16_kernel<2>, (const void *)gemm_xw256_s16_kernel<3>,
-                                  (const void *)gemm_xw256_s16_kernel<4>, (const void *)gemm_xw256_s16_kernel<5>};
+                                  (const void *)gemm_xw256_s16_kernel<4>, (const void *)gemm_xw256_s16_kernel<5>,
+                                  (const void *)gemm_xw256_s16_kernel<4, true>, (const void *)gemm_xw256_s16_kernel<5, true>};
             for (const void *k : tall) {
                 hipError_t ae = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS16LdsBytes);
                 if (ae != hipSuccess) return gcn_internal_fail_hip((int)ae, "gcn_gemm_xw256_f32_b3: LDS size");
@@ -2436,8 +2445,21 @@ static int xw256_launch(const char *who, int sch, const float *X, int64_t ldx, c
         hipLaunchKernelGGL((gemm_xw256_s16_kernel<3>), dim3(grid), dim3(kThreads), dyn, s, X, ldx,
                            (const unsigned char *)workspace, Y, ldy, M, (uint32_t *)y_absmax, ep);
         break;
-    case 4: GCN_LAUNCH_H2(4); break;
-    case 5: GCN_LAUNCH_H2(5); break;
+    case 4:
+    case 5:
+        if (s16 && ep.keep_bits_out != nullptr) {        // (+ the one-bit form of the result)
+            if (variant == 4)
+                hipLaunchKernelGGL((gemm_xw256_s16_kernel<4, true>), dim3(grid), dim3(kThreads), dyn, s, X, ldx,
+                                   (const unsigned char *)workspace, Y, ldy, M, (uint32_t *)y_absmax, ep);
+            else
+                hipLaunchKernelGGL((gemm_xw256_s16_kernel<5, true>), dim3(grid), dim3(kThreads), dyn, s, X, ldx,
+                                   (const unsigned char *)workspace, Y, ldy, M, (uint32_t *)y_absmax, ep);
+        } else if (variant == 4) {
+            GCN_LAUNCH_H2(4);
+        } else {
+            GCN_LAUNCH_H2(5);
+        }
+        break;
     default: GCN_LAUNCH_H2(6); break;
     }
 #undef GCN_LAUNCH_H2
