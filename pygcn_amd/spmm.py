@@ -1140,12 +1140,16 @@ class GraphConvFunction(torch.autograd.Function):
             if ctx.relu:
                 g = relu_dropout_backward(vals.contiguous(), out.index_select(0, rows), ctx.scale)
                 bound = bound * ctx.scale if bound is not None else None
-            grad_bias = None
-            if need_b:
+            grad_bias = grad_w = None
+            if need_b and need_w and f32 and g.is_contiguous():      # (both from ONE pass over g: weight_grad_rows)
+                both = weight_grad_rows(input, g, meta["padded"], None, ctx.z_bound, bound, n_list=rows.numel(),
+                                        colsum_g=True)
+                if both is not None:
+                    grad_w, grad_bias = both[0], both[1].to(dt)
+            if need_b and grad_bias is None:
                 sums = backward_with_colsum(g) if g.is_contiguous() else None
                 grad_bias = sums[1] if sums is not None else g.float().sum(0).to(dt)
-            grad_w = None
-            if need_w:
+            if need_w and grad_w is None:
                 grad_w = weight_grad_rows(input, g, meta["padded"], None, ctx.z_bound, bound,
                                           n_list=rows.numel()) if (f32 and (ctx.z_bound is not None or not gemm_needs_bounds())) else None
                 if grad_w is None:
