@@ -43,9 +43,9 @@ real_xw, real_wg = S.gemm_xw256, S.weight_grad_rows
 
 
 def rec_xw(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_scale=1.0, bias=None,
-           relu=False, dropout_p=0.0, seed=0, mask_rows=None, row_base=0):
+           relu=False, dropout_p=0.0, seed=0, mask_rows=None, row_base=0, **more):
     out = real_xw(X, W, x_bound, y_absmax, rows=rows, mask_src=mask_src, mask_scale=mask_scale, bias=bias,
-                  relu=relu, dropout_p=dropout_p, seed=seed, mask_rows=mask_rows, row_base=row_base)
+                  relu=relu, dropout_p=dropout_p, seed=seed, mask_rows=mask_rows, row_base=row_base, **more)
     if out is not None:
         calls.append(("xw", dict(X=X.detach(), W=W.detach().clone(), rows=rows,
                                  what=("forward + layer epilogue" if (bias is not None or relu) else
@@ -53,8 +53,8 @@ def rec_xw(X, W, x_bound=None, y_absmax=None, rows=None, mask_src=None, mask_sca
     return out
 
 
-def rec_wg(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None):
-    out = real_wg(A, G, rows_a, rows_g, a_bound, g_bound, n_list)
+def rec_wg(A, G, rows_a=None, rows_g=None, a_bound=None, g_bound=None, n_list=None, **more):
+    out = real_wg(A, G, rows_a, rows_g, a_bound, g_bound, n_list, **more)
     if out is not None and A.dtype == torch.float32:
         calls.append(("wg", dict(A=A.detach(), G=G.detach().clone(), rows_a=rows_a, rows_g=rows_g, n_list=n_list)))
     return out
