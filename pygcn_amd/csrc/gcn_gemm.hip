@@ -1357,19 +1357,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_xw256_s16_kernel(
                                        S16_SCHED == 0 ? 8 : S16_SCHED == 1 ? 9 : S16_SCHED == 2 ? 7 : 10,
                                        S16_SCHED == 0 ? 10 : S16_SCHED == 1 ? 11 : S16_SCHED == 2 ? 10 : 12,
                                        S16_SCHED == 0 ? 12 : S16_SCHED == 1 ? 13 : S16_SCHED == 2 ? 13 : 14};
-#ifndef S16_STAGGER       /* experiment builds: waves 4-7 (the SIMD partners of 0-3) place every piece one column block later */
-#define S16_STAGGER 0
-#endif
-                const bool late = S16_STAGGER && wave >= 4;                 // (uniform)
-                auto here = [&](int k) { return late ? cb == at[k] + 1 : cb == at[k]; };
                 if (SPREAD) {
-                    if (here(0)) issue_w_pair(0);
-                    if (here(1)) issue_w_pair(1);
-                    if (here(2)) issue_w_pair(2);
-                    if (here(3)) issue_x();
-                    if (here(4)) store_one(0);
-                    if (here(5)) store_one(1);
-                    if (here(6) && issued_w) {
+                    if (cb == at[0]) issue_w_pair(0);
+                    if (cb == at[1]) issue_w_pair(1);
+                    if (cb == at[2]) issue_w_pair(2);
+                    if (cb == at[3]) issue_x();
+                    if (cb == at[4]) store_one(0);
+                    if (cb == at[5]) store_one(1);
+                    if (cb == at[6] && issued_w) {
                         // younger than the chunk's two DMA instructions (at least): this stage's 6 W pieces,
                         // its X chunk and its stores
                         if (issued_x) { if (have_prev) dma_wait<10>(); else dma_wait<8>(); }
